@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + shadow + reflection + refraction rays) and frame
+time of the render hot path on SPD-style balls (sphereflake size 4) at 3840x2160.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A step = one frame: every rank traces its interleaved 8x8 tiles of
+the same image (full scene copy per GPU), the u8 tile buffers are gathered to rank 0 with
+RCCL, rank 0 de-interleaves them into the row-major image.  The image is fixed as N
+grows (strong scaling).  Scene parse, tree build and upload happen before the timed
+region; inputs are resident in HBM when it starts and the finished image stays in HBM.
+
+Rank 0 prints one JSON line.  Besides the contract fields it carries
+  roofline      VALU roofline of the trace kernels (this path has no dense contraction
+                and its scene data is cache resident, so neither "mfma" nor "hbm" binds):
+                algorithmic FLOPs per frame (work counters x per-event coefficients)
+                / summed trace-kernel time per frame (HIP events on the launch stream),
+                against the 157.3 TFLOP/s f32 vector peak; the HBM view alongside.
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm; the reference itself
+                is Rust and cannot be built here) timed on this host on a bounded sample
+                of rows of the same frame.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# FLOPs and bytes per counted event, from the reference's source (add/sub/mul/div/sqrt/
+# compare = 1 each): node visit = BoundingBox::intersect (src/shape.rs:96-171) on one
+# 64-byte node; sphere test to the discriminant / extra on a hit (src/sphere.rs:49-75);
+# cone (src/cone.rs:115-214); polygon plane test / per edge-loop / per edge / on a hit
+# (src/polygon.rs:61-289); per light at a front-face hit (src/scene.rs:104-123); shade
+# evaluation (src/phong.rs:35-62); per surface hit (src/scene.rs:95-96, :195); spawn of a
+# reflection / refraction ray (src/vector_math.rs:51-73, src/scene.rs:128-191); primary ray
+# generation (src/render.rs:101-108).
+FLOP = {"node_visits": 27, "interior_steps": 4, "sphere_tests": 26, "sphere_hits": 25, "cone_tests": 123,
+        "cone_hits": 51, "poly_tests": 32, "poly_edge_loops": 12, "poly_edges": 15, "poly_hits": 92,
+        "light_evals": 16, "shade_evals": 37, "surface_hits": 15, "rays_reflect": 20, "rays_refract": 31,
+        "rays_primary": 25}
+BYTES = {"node_visits": 64, "sphere_tests": 16, "cone_tests": 32, "poly_edges": 24, "light_evals": 24,
+         "shade_evals": 36}
+RAY_STATE_BYTES = 2 * 64   # one 32-byte ray record + one 32-byte node record, written then read
+FRAMEBUFFER_BYTES = 3      # u8 RGB per pixel
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="balls")
+    ap.add_argument("--size", type=int, default=4)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--fp", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--cpu-rows", type=int, default=8, help="rows of the frame the CPU baseline renders per leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rtamd = importlib.import_module("rust-raytracer_amd")
+    spd = importlib.import_module("rust-raytracer_amd.spd")
+    W, H = args.width, args.height
+    gen_kw = {"size": args.size} if args.scene in ("balls", "tetra", "rings", "mount") else {}
+    text = spd.GENERATORS[args.scene](width=W, height=H, **gen_kw)
+
+    ctx = rtamd.Context(local_rank)
+    t0 = time.perf_counter()
+    scene = rtamd.Scene.from_nff(ctx, text, build_threads=min(16, os.cpu_count() or 1))
+    setup_s = time.perf_counter() - t0
+    ti = scene.tree_info
+    fp_mode = rtamd.FP_EXACT if args.fp == "exact" else rtamd.FP_FAST
+    opt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    image = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
+    if world > 1:
+        stride = rtamd.tile_pixels_max(W, H, world)
+        mine = torch.zeros((stride, 3), dtype=torch.uint8, device="cuda")
+        gathered = torch.zeros((world, stride, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
+        parts = list(gathered.unbind(0)) if rank == 0 else None
+
+    def step():
+        if world == 1:
+            return scene.render_device(opt, None, image.data_ptr(), stream)
+        st = scene.render_device(opt, None, mine.data_ptr(), stream)
+        dist.gather(mine, parts, dst=0)
+        if rank == 0:
+            ctx.deinterleave(W, H, world, stride, 1, gathered.data_ptr(), image.data_ptr(), stream)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    st = stats[-1]
+    local = torch.tensor([elapsed, float(st.rays_total), float(st.rays_primary), float(st.rays_shadow),
+                          float(st.rays_reflect), float(st.rays_refract),
+                          float(np.mean([s.ms_trace for s in stats])), float(np.mean([s.ms_resolve for s in stats])),
+                          float(np.mean([s.ms_frame for s in stats]))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = local.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = local.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    else:
+        mx, sm = local, local
+    mx, sm = mx.cpu().numpy(), sm.cpu().numpy()
+    elapsed_max = float(mx[0])
+    rays_frame = float(sm[1])
+
+    # ---- work counters for the roofline: one instrumented frame, outside the timed region
+    wopt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world,
+                               collect_work=True)
+    wst = scene.render_device(wopt, None, (image if world == 1 else mine).data_ptr(), stream)
+    work = wst.as_dict()
+    wvec = torch.tensor([float(work[k]) for k in sorted(work)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(wvec, op=dist.ReduceOp.SUM)
+    work = dict(zip(sorted(work), (float(x) for x in wvec.cpu().numpy())))
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    flops = sum(work[k] * c for k, c in FLOP.items())
+    nodes_frame = work["rays_primary"] + work["rays_reflect"] + work["rays_refract"]
+    abytes = sum(work[k] * c for k, c in BYTES.items()) + nodes_frame * RAY_STATE_BYTES + W * H * FRAMEBUFFER_BYTES
+    trace_s = float(mx[6]) * 1e-3      # slowest rank's summed trace-kernel time per frame
+    ms_per_step = elapsed_max / args.steps * 1e3
+    value = rays_frame * args.steps / elapsed_max / 1e6
+
+    out = {
+        "metric": "Mrays/s (all ray types), SPD balls @3840x2160",
+        "value": round(value, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"SPD-style {args.scene} size {args.size} ({ti.n_leaf_refs} leaf refs in {ti.n_nodes} nodes, "
+                        f"depth {ti.max_depth}, largest leaf {ti.max_leaf}), {W}x{H}, max_depth {args.depth}, "
+                        f"Phong, fp_mode {args.fp}",
+            "parallelism": f"interleaved 8x8 tiles over {world} GPU(s), RCCL gather to rank 0" if world > 1
+                           else "single GPU, whole image",
+            "rays_per_frame": {"primary": int(sm[2]), "shadow": int(sm[3]), "reflect": int(sm[4]),
+                               "refract": int(sm[5]), "total": int(rays_frame)},
+            "setup_s": round(setup_s, 3), "tree_build_ms": round(ti.build_ms, 1),
+        },
+        "frame_ms": {"trace_kernels": round(float(mx[6]), 4), "resolve_kernels": round(float(mx[7]), 4),
+                     "device_frame": round(float(mx[8]), 4), "step_wall": round(ms_per_step, 4)},
+        "roofline": {
+            "bound": "valu",
+            "kernel": "k_trace (all bounce levels of one frame)",
+            "achieved": round(flops / trace_s / 1e12, 4),
+            "peak": PEAK_F32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(flops / trace_s / 1e12 / PEAK_F32_TFLOPS, 5),
+            "traffic": None,
+            "algorithmic_flops_per_frame": flops,
+            "algorithmic_bytes_per_frame": abytes,
+            "hbm_achieved_GBs": round(abytes / trace_s / 1e9, 3),
+            "hbm_peak_GBs": PEAK_HBM_GBS,
+            "hbm_frac": round(abytes / trace_s / 1e9 / PEAK_HBM_GBS, 6),
+            "work": {k: int(v) for k, v in work.items()},
+        },
+    }
+
+    if not args.no_cpu:
+        out["cpu_baseline"], out["parity_sample"] = cpu_baseline(args, text, image)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, text, image):
+    """Times the oracle on evenly spaced rows of the same frame (1 thread = what the
+    single-threaded reference does; then all host cores, rows in parallel) and compares
+    those rows with the GPU image."""
+    from oracle import oracle
+    W, H = args.width, args.height
+    cores = min(16, os.cpu_count() or 1)
+    o = oracle.OracleScene(text, build_threads=cores)
+    rows1 = max(1, args.cpu_rows)
+    step1 = max(1, H // rows1)
+    _, u1, c1, ms1 = o.render(W, H, max_depth=args.depth, row_start=step1 // 2, row_step=step1, threads=1,
+                              want_f32=False)
+    rays1 = sum(c1[k] for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"))
+    rowsn = rows1 * cores
+    stepn = max(1, H // rowsn)
+    _, un, cn, msn = o.render(W, H, max_depth=args.depth, row_start=stepn // 2, row_step=stepn, threads=cores,
+                              want_f32=False)
+    raysn = sum(cn[k] for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"))
+    gpu = image.cpu().numpy()
+    sel = slice(stepn // 2, None, stepn)
+    d = np.abs(gpu[sel].astype(np.int32) - un[sel].astype(np.int32)).reshape(-1, 3).max(axis=1)
+    base = {
+        "value": round(raysn / msn / 1e3, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"{len(range(stepn // 2, H, stepn))} evenly spaced rows of the same {W}x{H} frame "
+                  f"({int(raysn)} rays, {msn / 1e3:.1f} s on {cores} threads); tree build {o.info.build_ms:.0f} ms excluded",
+        "single_thread": {"value": round(rays1 / ms1 / 1e3, 4), "cores": 1,
+                          "sample": f"{len(range(step1 // 2, H, step1))} rows ({int(rays1)} rays, {ms1 / 1e3:.1f} s)"},
+    }
+    parity = {"pixels": int(d.size), "differing_fraction": float((d > 0).mean()),
+              "over_1_lsb_fraction": float((d > 1).mean()), "max_diff": int(d.max()),
+              "against": "CPU oracle (libm powf) on the cpu_baseline rows"}
+    return base, parity
+
+
+if __name__ == "__main__":
+    main()

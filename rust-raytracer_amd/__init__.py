@@ -1,0 +1,452 @@
+"""Python host side of librtamd.so (ctypes over the C ABI declared in include/rtamd.h).
+
+Mirrors the reference's call sequence for the render path
+(/root/reference/src/main.rs:36-43): ``nff::read`` -> ``render::render`` -> ``ppm::write``
+become ``Scene.from_nff`` -> ``Scene.render`` -> ``write_ppm``.  There is no CPU fallback:
+every render goes through the HIP kernels, and loading fails loudly if the shared
+library has not been built (``make -C rust-raytracer_amd``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtamd.so")
+
+RT_OK = 0
+RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_BUILD, RT_ERR_PARSE, RT_ERR_IO, RT_ERR_CAPACITY = (
+    -1, -2, -3, -4, -5, -6, -7)
+FP_EXACT, FP_FAST = 0, 1
+KIND_SPHERE, KIND_CONE, KIND_POLYGON = 0, 1, 2
+NO_PRIM = 0xFFFFFFFF
+
+WORK_NAMES = ("node_visits", "interior_steps", "sphere_tests", "sphere_hits", "cone_tests", "cone_hits",
+              "poly_tests", "poly_edge_loops", "poly_edges", "poly_hits", "light_evals", "shade_evals", "surface_hits")
+
+OP_AABB, OP_SPHERE, OP_CONE, OP_POLYGON, OP_PHONG, OP_BLINN, OP_REFLECT, OP_REFRACT, OP_POW, OP_QUANTIZE = range(10)
+
+# every symbol include/rtamd.h declares
+EXPORTED_SYMBOLS = (
+    "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create", "rt_scene_destroy",
+    "rt_scene_tree_info", "rt_scene_tree_copy", "rt_render", "rt_render_device", "rt_tile_pixels",
+    "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
+    "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
+    "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
+)
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librtamd error {code}: {msg}")
+        self.code = code
+
+
+class rt_view(C.Structure):
+    _fields_ = [("from_", C.c_float * 3), ("at", C.c_float * 3), ("up", C.c_float * 3), ("angle", C.c_float),
+                ("hither", C.c_float), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class rt_sphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float)]
+
+
+class rt_cone(C.Structure):
+    _fields_ = [("base", C.c_float * 3), ("base_radius", C.c_float), ("apex", C.c_float * 3),
+                ("apex_radius", C.c_float)]
+
+
+class rt_vertex(C.Structure):
+    _fields_ = [("point", C.c_float * 3), ("normal", C.c_float * 3)]
+
+
+class rt_polygon(C.Structure):
+    _fields_ = [("first_vertex", C.c_uint32), ("vertex_count", C.c_uint32)]
+
+
+class rt_surface(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("kd", C.c_float), ("ks", C.c_float), ("shine", C.c_float),
+                ("reflectance", C.c_float), ("transmittance", C.c_float), ("ior", C.c_float), ("model", C.c_uint32)]
+
+
+class rt_light(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("color", C.c_float * 3)]
+
+
+class rt_primitive(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("surface", C.c_uint32)]
+
+
+class rt_kd_node(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("plane", C.c_float), ("bmax", C.c_float * 3), ("axis", C.c_uint32),
+                ("under", C.c_uint32), ("over", C.c_uint32), ("parent", C.c_uint32), ("depth", C.c_uint32),
+                ("extent", C.c_float * 3), ("pad", C.c_uint32)]
+
+
+NODE_DTYPE = np.dtype([("bmin", np.float32, 3), ("plane", np.float32), ("bmax", np.float32, 3), ("axis", np.uint32),
+                       ("under", np.uint32), ("over", np.uint32), ("parent", np.uint32), ("depth", np.uint32),
+                       ("extent", np.float32, 3), ("pad", np.uint32)])
+assert NODE_DTYPE.itemsize == 64 and C.sizeof(rt_kd_node) == 64
+
+
+class rt_scene_desc(C.Structure):
+    _fields_ = [("n_spheres", C.c_uint32), ("n_cones", C.c_uint32), ("n_polygons", C.c_uint32),
+                ("n_vertices", C.c_uint32), ("n_primitives", C.c_uint32), ("n_surfaces", C.c_uint32),
+                ("n_lights", C.c_uint32),
+                ("spheres", C.POINTER(rt_sphere)), ("cones", C.POINTER(rt_cone)), ("polygons", C.POINTER(rt_polygon)),
+                ("vertices", C.POINTER(rt_vertex)), ("primitives", C.POINTER(rt_primitive)),
+                ("surfaces", C.POINTER(rt_surface)), ("lights", C.POINTER(rt_light)),
+                ("background", C.c_float * 3),
+                ("n_nodes", C.c_uint32), ("n_leaf_refs", C.c_uint32),
+                ("nodes", C.POINTER(rt_kd_node)), ("leaf_refs", C.POINTER(C.c_uint32)),
+                ("build_threads", C.c_uint32)]
+
+
+class rt_options(C.Structure):
+    _fields_ = [("max_depth", C.c_uint32), ("min_contribution", C.c_float), ("fp_mode", C.c_uint32),
+                ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32), ("collect_work", C.c_uint32)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
+                ("rays_refract", C.c_uint64), ("work", C.c_uint64 * 13), ("ray_nodes", C.c_uint64),
+                ("levels", C.c_uint32), ("retries", C.c_uint32), ("ms_trace", C.c_double), ("ms_resolve", C.c_double),
+                ("ms_frame", C.c_double), ("ms_d2h", C.c_double)]
+
+    @property
+    def rays_total(self):
+        return self.rays_primary + self.rays_shadow + self.rays_reflect + self.rays_refract
+
+    def as_dict(self):
+        d = {"rays_primary": self.rays_primary, "rays_shadow": self.rays_shadow, "rays_reflect": self.rays_reflect,
+             "rays_refract": self.rays_refract}
+        d.update({n: int(self.work[i]) for i, n in enumerate(WORK_NAMES)})
+        return d
+
+
+class rt_tree_info(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_leaf_refs", C.c_uint32),
+                ("max_depth", C.c_uint32), ("max_leaf", C.c_uint32), ("build_ms", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `make -C {_HERE}` (hipcc, gfx950)")
+    # PyTorch wheels carry their own HIP runtime (torch/lib/libamdhip64.so, soname
+    # libamdhip64.so.7).  A process must use ONE HIP runtime: device pointers, streams and
+    # events are only meaningful inside the runtime that made them.  Loading torch first makes
+    # the dynamic loader satisfy this library's libamdhip64.so.7 dependency with torch's copy,
+    # so torch tensors / RCCL buffers and this library's kernels share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rt_context_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    L.rt_context_destroy.argtypes = [vp]
+    L.rt_context_destroy.restype = None
+    L.rt_last_error.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_scene_create.argtypes = [vp, C.POINTER(rt_scene_desc), C.POINTER(vp)]
+    L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_destroy.restype = None
+    L.rt_scene_tree_info.argtypes = [vp, C.POINTER(rt_tree_info)]
+    L.rt_scene_tree_copy.argtypes = [vp, vp, vp]
+    L.rt_render.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, C.POINTER(rt_stats)]
+    L.rt_render_device.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, vp, C.POINTER(rt_stats)]
+    for f in (L.rt_tile_pixels, L.rt_tile_pixels_max, L.rt_tile_slot):
+        f.restype = C.c_uint64
+    L.rt_tile_pixels.argtypes = [C.c_uint32] * 4
+    L.rt_tile_pixels_max.argtypes = [C.c_uint32] * 3
+    L.rt_tile_slot.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32)]
+    L.rt_deinterleave_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, vp]
+    L.rt_deinterleave_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp]
+    L.rt_nff_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rt_parsed_desc.argtypes = [vp]
+    L.rt_parsed_desc.restype = C.POINTER(rt_scene_desc)
+    L.rt_parsed_view.argtypes = [vp]
+    L.rt_parsed_view.restype = C.POINTER(rt_view)
+    L.rt_parsed_warning_count.argtypes = [vp]
+    L.rt_parsed_warning_count.restype = C.c_uint32
+    L.rt_parsed_free.argtypes = [vp]
+    L.rt_parsed_free.restype = None
+    L.rt_ppm_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    L.rt_tree_build.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.rt_tree_get.argtypes = [vp, C.POINTER(rt_tree_info), C.POINTER(C.POINTER(rt_kd_node)),
+                              C.POINTER(C.POINTER(C.c_uint32))]
+    L.rt_tree_free.argtypes = [vp]
+    L.rt_tree_free.restype = None
+    L.rt_camera_basis.argtypes = [C.POINTER(rt_view), vp]
+    L.rt_camera_basis.restype = None
+    L.rt_debug_intersect.argtypes = [vp, vp, C.c_uint32, C.c_uint64] + [vp] * 7
+    L.rt_debug_eval.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _struct_array(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(C.addressof(ptr.contents))
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class ParsedScene:
+    """NFF text parsed by the library's front end (reference src/nff.rs:348 ``read``)."""
+
+    def __init__(self, nff_text, use_phong: bool = True):
+        if isinstance(nff_text, str):
+            nff_text = nff_text.encode()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().rt_nff_parse(nff_text, len(nff_text), int(use_phong), C.byref(h), err, 512)
+        if rc != RT_OK:
+            raise RtError(rc, err.value.decode())
+        self._h = h
+        self.desc = lib().rt_parsed_desc(h).contents
+        self.view = lib().rt_parsed_view(h).contents
+        self.warnings = lib().rt_parsed_warning_count(h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().rt_parsed_free(h)
+            self._h = None
+
+    def arrays(self):
+        """Flat copies of the parsed scene, for checks against the oracle's parser."""
+        d = self.desc
+        f = np.float32
+        sphere_dt = np.dtype([("center", f, 3), ("radius", f)])
+        cone_dt = np.dtype([("base", f, 3), ("base_radius", f), ("apex", f, 3), ("apex_radius", f)])
+        vertex_dt = np.dtype([("point", f, 3), ("normal", f, 3)])
+        poly_dt = np.dtype([("first_vertex", np.uint32), ("vertex_count", np.uint32)])
+        surf_dt = np.dtype([("color", f, 3), ("kd", f), ("ks", f), ("shine", f), ("reflectance", f),
+                            ("transmittance", f), ("ior", f), ("model", np.uint32)])
+        light_dt = np.dtype([("position", f, 3), ("color", f, 3)])
+        prim_dt = np.dtype([("kind", np.uint32), ("index", np.uint32), ("surface", np.uint32)])
+        return {
+            "spheres": _struct_array(d.spheres, d.n_spheres, sphere_dt),
+            "cones": _struct_array(d.cones, d.n_cones, cone_dt),
+            "vertices": _struct_array(d.vertices, d.n_vertices, vertex_dt),
+            "polygons": _struct_array(d.polygons, d.n_polygons, poly_dt),
+            "surfaces": _struct_array(d.surfaces, d.n_surfaces, surf_dt),
+            "lights": _struct_array(d.lights, d.n_lights, light_dt),
+            "primitives": _struct_array(d.primitives, d.n_primitives, prim_dt),
+            "background": np.array(list(d.background), dtype=f),
+        }
+
+    def build_tree(self, threads: int = 1):
+        """Host-only exact partition build; returns (info, nodes, leaf_refs)."""
+        desc = rt_scene_desc.from_buffer_copy(self.desc)
+        desc.build_threads = threads
+        t = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().rt_tree_build(C.byref(desc), C.byref(t), err, 512)
+        if rc != RT_OK:
+            raise RtError(rc, err.value.decode())
+        info = rt_tree_info()
+        nodes_p = C.POINTER(rt_kd_node)()
+        refs_p = C.POINTER(C.c_uint32)()
+        lib().rt_tree_get(t, C.byref(info), C.byref(nodes_p), C.byref(refs_p))
+        nodes = _struct_array(nodes_p, info.n_nodes, NODE_DTYPE)
+        refs = np.ctypeslib.as_array(refs_p, shape=(info.n_leaf_refs,)).copy() if info.n_leaf_refs else np.zeros(
+            0, dtype=np.uint32)
+        lib().rt_tree_free(t)
+        return info, nodes, refs
+
+    def camera_basis(self, width=0, height=0):
+        v = rt_view.from_buffer_copy(self.view)
+        if width:
+            v.width = width
+        if height:
+            v.height = height
+        out = np.zeros(9, dtype=np.float32)
+        lib().rt_camera_basis(C.byref(v), _ptr(out))
+        return out.reshape(3, 3)
+
+
+class Context:
+    """One GPU (rt_context)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        ids = (C.c_int * 1)(device)
+        rc = lib().rt_context_create(1, ids, C.byref(h))
+        self._h = h
+        if rc != RT_OK:
+            msg = lib().rt_last_error(h).decode() if h else "context allocation failed"
+            if h:
+                lib().rt_context_destroy(h)
+            self._h = None
+            raise RtError(rc, msg)
+        self.device = device
+
+    def check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, lib().rt_last_error(self._h).decode())
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().rt_context_destroy(h)
+            self._h = None
+
+    def debug_eval(self, op, rows, out_cols, fp_mode=FP_EXACT, verts=None):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n, stride = rows.shape
+        out = np.zeros((n, out_cols), dtype=np.float32)
+        vp, nv = None, 0
+        if verts is not None:
+            verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 6)
+            vp, nv = _ptr(verts), verts.shape[0]
+        self.check(lib().rt_debug_eval(self._h, op, fp_mode, n, _ptr(rows), stride, _ptr(out), out_cols, vp, nv))
+        return out
+
+    def deinterleave(self, width, height, count, stride_pixels, elem_size, d_gathered, d_image, stream=None):
+        self.check(lib().rt_deinterleave_device(self._h, width, height, count, stride_pixels, elem_size, d_gathered,
+                                                d_image, stream))
+
+
+@dataclass
+class RenderOptions:
+    max_depth: int = 5           # MAX_DEPTH, reference src/scene.rs:8
+    min_contribution: float = 0.003  # MIN_CONTRIBUTION, reference src/scene.rs:9
+    fp_mode: int = FP_EXACT
+    tile_rank: int = 0
+    tile_count: int = 1
+    collect_work: bool = False
+
+    def c(self):
+        return rt_options(self.max_depth, self.min_contribution, self.fp_mode, self.tile_rank, self.tile_count,
+                          int(self.collect_work))
+
+
+class Scene:
+    """A scene resident on one GPU with its space partition (rt_scene)."""
+
+    def __init__(self, ctx: Context, parsed: ParsedScene, build_threads: int = 1):
+        self.ctx = ctx
+        self.parsed = parsed
+        desc = rt_scene_desc.from_buffer_copy(parsed.desc)
+        desc.build_threads = build_threads
+        h = C.c_void_p()
+        ctx.check(lib().rt_scene_create(ctx._h, C.byref(desc), C.byref(h)))
+        self._h = h
+        self.tree_info = rt_tree_info()
+        lib().rt_scene_tree_info(h, C.byref(self.tree_info))
+
+    @classmethod
+    def from_nff(cls, ctx: Context, nff_text, use_phong: bool = True, build_threads: int = 1):
+        return cls(ctx, ParsedScene(nff_text, use_phong), build_threads)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().rt_scene_destroy(h)
+            self._h = None
+
+    def view(self, width=0, height=0):
+        v = rt_view.from_buffer_copy(self.parsed.view)
+        if width:
+            v.width = width
+        if height:
+            v.height = height
+        return v
+
+    def tree(self):
+        ti = self.tree_info
+        nodes = np.zeros(ti.n_nodes, dtype=NODE_DTYPE)
+        refs = np.zeros(max(ti.n_leaf_refs, 1), dtype=np.uint32)
+        lib().rt_scene_tree_copy(self._h, _ptr(nodes), _ptr(refs))
+        return nodes, refs[: ti.n_leaf_refs]
+
+    def render(self, opt: Optional[RenderOptions] = None, width=0, height=0, want_f32=True, want_u8=True):
+        """Replaces render::render (reference src/render.rs:72).  Returns (f32 [H,W,3] | None,
+        u8 [H,W,3] | None, rt_stats); with tile_count > 1 the arrays are the compact tile
+        buffers [n_slots, 3] of this rank instead."""
+        opt = opt or RenderOptions()
+        v = self.view(width, height)
+        if opt.tile_count > 1:
+            n = lib().rt_tile_pixels(v.width, v.height, opt.tile_rank, opt.tile_count)
+            shape = (n, 3)
+        else:
+            shape = (v.height, v.width, 3)
+        f32 = np.zeros(shape, dtype=np.float32) if want_f32 else None
+        u8 = np.zeros(shape, dtype=np.uint8) if want_u8 else None
+        st = rt_stats()
+        o = opt.c()
+        self.ctx.check(lib().rt_render(self.ctx._h, self._h, C.byref(v), C.byref(o), _ptr(f32), _ptr(u8), C.byref(st)))
+        return f32, u8, st
+
+    def render_device(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0):
+        """Device-pointer form (ints or None); returns rt_stats after the frame completed."""
+        v = self.view(width, height)
+        st = rt_stats()
+        o = opt.c()
+        self.ctx.check(lib().rt_render_device(self.ctx._h, self._h, C.byref(v), C.byref(o), d_f32, d_u8, stream,
+                                              C.byref(st)))
+        return st
+
+    def debug_intersect(self, src, ray, near, ignore, fp_mode=FP_EXACT):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        ray = np.ascontiguousarray(ray, dtype=np.float32)
+        near = np.ascontiguousarray(near, dtype=np.float32)
+        ignore = np.ascontiguousarray(ignore, dtype=np.uint32)
+        n = src.shape[0]
+        prim = np.zeros(n, dtype=np.uint32)
+        dist = np.zeros(n, dtype=np.float32)
+        normal = np.zeros((n, 3), dtype=np.float32)
+        self.ctx.check(lib().rt_debug_intersect(self.ctx._h, self._h, fp_mode, n, _ptr(src), _ptr(ray), _ptr(near),
+                                                _ptr(ignore), _ptr(prim), _ptr(dist), _ptr(normal)))
+        return prim, dist, normal
+
+
+def write_ppm(path: str, rgb_u8: np.ndarray):
+    """reference src/ppm.rs:8 ``write``."""
+    rgb_u8 = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+    h, w, _ = rgb_u8.shape
+    rc = lib().rt_ppm_write(path.encode(), w, h, _ptr(rgb_u8))
+    if rc != RT_OK:
+        raise RtError(rc, f"cannot write {path}")
+
+
+def tile_pixels(width, height, rank, count):
+    return int(lib().rt_tile_pixels(width, height, rank, count))
+
+
+def tile_pixels_max(width, height, count):
+    return int(lib().rt_tile_pixels_max(width, height, count))
+
+
+def tile_slot(width, height, count, x, y):
+    r = C.c_uint32(0)
+    s = lib().rt_tile_slot(width, height, count, x, y, C.byref(r))
+    return int(s), int(r.value)
+
+
+def deinterleave_host(width, height, count, gathered: np.ndarray):
+    """gathered: [count, stride_pixels, 3] u8 or f32 -> [H, W, 3]."""
+    gathered = np.ascontiguousarray(gathered)
+    stride = gathered.shape[1]
+    out = np.zeros((height, width, 3), dtype=gathered.dtype)
+    rc = lib().rt_deinterleave_host(width, height, count, stride, gathered.dtype.itemsize, _ptr(gathered), _ptr(out))
+    if rc != RT_OK:
+        raise RtError(rc, "rt_deinterleave_host")
+    return out

@@ -1,0 +1,516 @@
+// C ABI of librtamd.so: contexts, scene upload, frame orchestration, diagnostics.
+// Host code only; kernels live in rt_kernels.hip (built twice: rt_exact, rt_fast).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rt_host.h"
+#include "rt_launch.h"
+
+using namespace rtamd;
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        else p = nullptr;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess) return e;
+        if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+}  // namespace
+
+struct rt_context {
+    int device = 0;
+    std::string err;
+    // frame workspace, kept across calls and grown on demand
+    DevBuf<float4> ray_o, ray_d, node_col;
+    DevBuf<uint4> node_kid;
+    DevBuf<uint32_t> levels;  // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | overflow
+    DevBuf<unsigned long long> counters;
+    size_t pool_cap = 0;
+    DevBuf<float> out_f32;
+    DevBuf<uint8_t> out_u8;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool kernels_ready = false;
+};
+
+struct rt_scene {
+    rt_context* ctx = nullptr;
+    SceneData data;
+    HostTree tree;
+    DevBuf<uint4> nodes, leaf_items;
+    DevBuf<float4> cones, vpos, vnrm, surfaces, lights;
+    DevBuf<uint32_t> prim_surface;
+    DevScene dev{};
+};
+
+namespace {
+
+int fail(rt_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(ctx, RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+float4 f4(const float* v, float w) { return make_float4(v[0], v[1], v[2], w); }
+float bits_to_float(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int ensure_pool(rt_context* ctx, size_t cap) {
+    if (ctx->pool_cap >= cap) return RT_OK;
+    RT_HIP(ctx, ctx->ray_o.alloc(cap));
+    RT_HIP(ctx, ctx->ray_d.alloc(cap));
+    RT_HIP(ctx, ctx->node_col.alloc(cap));
+    RT_HIP(ctx, ctx->node_kid.alloc(cap));
+    ctx->pool_cap = cap;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_context** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    rt_context* ctx = new rt_context();
+    *out = ctx;  // returned even on failure so the message can be read; destroy it afterwards
+    if (n_devices != 1)
+        return fail(ctx, RT_ERR_UNSUPPORTED,
+                    "a context drives one GPU: create one context per process and GPU and partition the image "
+                    "with rt_options.tile_rank / tile_count");
+    int count = 0;
+    RT_HIP(ctx, hipGetDeviceCount(&count));
+    ctx->device = device_ids ? device_ids[0] : 0;
+    if (ctx->device < 0 || ctx->device >= count) return fail(ctx, RT_ERR_INVALID, "device id out of range");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    RT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ctx, RT_ERR_UNSUPPORTED, std::string("librtamd is built for gfx950 only; device is ") + prop.gcnArchName);
+    for (auto& e : ctx->ev) RT_HIP(ctx, hipEventCreate(&e));
+    RT_HIP(ctx, ctx->levels.alloc(2 * RT_MAX_LEVELS + 1));
+    RT_HIP(ctx, ctx->counters.alloc(17));
+    return RT_OK;
+}
+
+extern "C" void rt_context_destroy(rt_context* ctx) {
+    if (!ctx) return;
+    for (auto& e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+extern "C" const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_scene** out) {
+    if (!ctx || !desc || !out) return fail(ctx, RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::string err;
+    int rc = validate_desc(*desc, err);
+    if (rc != RT_OK) return fail(ctx, rc, err);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+
+    std::unique_ptr<rt_scene> sc(new rt_scene());
+    sc->ctx = ctx;
+    sc->data.assign(*desc);
+    if (desc->nodes) {  // adopt the caller's partition
+        sc->tree.nodes.assign(desc->nodes, desc->nodes + desc->n_nodes);
+        sc->tree.refs.assign(desc->leaf_refs, desc->leaf_refs + desc->n_leaf_refs);
+        rt_tree_info& ti = sc->tree.info;
+        ti.n_nodes = desc->n_nodes;
+        ti.n_leaf_refs = desc->n_leaf_refs;
+        // depth by walking down from the root (children always follow their parent)
+        std::vector<uint32_t> depth(desc->n_nodes, 0);
+        for (uint32_t i = 0; i < desc->n_nodes; ++i) {
+            const rt_kd_node& n = desc->nodes[i];
+            if (n.axis == 3) {
+                ti.n_leaves++;
+                ti.max_leaf = std::max(ti.max_leaf, n.over);
+            } else {
+                depth[n.under] = depth[n.over] = depth[i] + 1;
+            }
+            ti.max_depth = std::max(ti.max_depth, depth[i]);
+        }
+    } else {
+        rt_scene_desc d = sc->data.desc;
+        d.build_threads = desc->build_threads;
+        rc = build_tree(d, sc->tree, err);
+        if (rc != RT_OK) return fail(ctx, rc, err);
+    }
+
+    const SceneData& sd = sc->data;
+    // leaf entries, in the builder's list order (src/space_partition.rs:348-385 walks them in order)
+    std::vector<uint4> items(sc->tree.refs.size() * 2);
+    for (size_t k = 0; k < sc->tree.refs.size(); ++k) {
+        const uint32_t prim = sc->tree.refs[k];
+        const rt_primitive& p = sd.primitives[prim];
+        uint4 head = make_uint4(prim, p.kind, p.index, 0);
+        uint4 body = make_uint4(0, 0, 0, 0);
+        if (p.kind == RT_KIND_SPHERE) {
+            const rt_sphere& s = sd.spheres[p.index];
+            memcpy(&body.x, s.center, 12);
+            memcpy(&body.w, &s.radius, 4);
+        } else if (p.kind == RT_KIND_POLYGON) {
+            head.z = sd.polygons[p.index].first_vertex;
+            head.w = sd.polygons[p.index].vertex_count;
+        }
+        items[2 * k] = head;
+        items[2 * k + 1] = body;
+    }
+    std::vector<uint4> nodes(sc->tree.nodes.size() * 4);
+    static_assert(sizeof(rt_kd_node) == 64, "node layout");
+    memcpy(nodes.data(), sc->tree.nodes.data(), sc->tree.nodes.size() * sizeof(rt_kd_node));
+
+    std::vector<float4> cones, vpos, vnrm, surfaces, lights;
+    for (const rt_cone& c : sd.cones) {
+        cones.push_back(f4(c.base, c.base_radius));
+        cones.push_back(f4(c.apex, c.apex_radius));
+    }
+    for (const rt_vertex& v : sd.vertices) {
+        vpos.push_back(f4(v.point, 0.0f));
+        vnrm.push_back(f4(v.normal, 0.0f));
+    }
+    for (const rt_surface& s : sd.surfaces) {
+        surfaces.push_back(f4(s.color, s.kd));
+        surfaces.push_back(make_float4(s.ks, s.shine, s.reflectance, s.transmittance));
+        surfaces.push_back(make_float4(s.ior, bits_to_float(s.model), 0.0f, 0.0f));
+    }
+    for (const rt_light& l : sd.lights) {
+        lights.push_back(f4(l.position, 0.0f));
+        lights.push_back(f4(l.color, 0.0f));
+    }
+    std::vector<uint32_t> prim_surface;
+    for (const rt_primitive& p : sd.primitives) prim_surface.push_back(p.surface);
+
+    RT_HIP(ctx, sc->nodes.upload(nodes));
+    RT_HIP(ctx, sc->leaf_items.upload(items));
+    RT_HIP(ctx, sc->cones.upload(cones));
+    RT_HIP(ctx, sc->vpos.upload(vpos));
+    RT_HIP(ctx, sc->vnrm.upload(vnrm));
+    RT_HIP(ctx, sc->surfaces.upload(surfaces));
+    RT_HIP(ctx, sc->lights.upload(lights));
+    RT_HIP(ctx, sc->prim_surface.upload(prim_surface));
+
+    DevScene& d = sc->dev;
+    d.nodes = sc->nodes.p;
+    d.leaf_items = sc->leaf_items.p;
+    d.cones = sc->cones.p;
+    d.vpos = sc->vpos.p;
+    d.vnrm = sc->vnrm.p;
+    d.surfaces = sc->surfaces.p;
+    d.prim_surface = sc->prim_surface.p;
+    d.lights = sc->lights.p;
+    d.n_lights = (uint32_t)sd.lights.size();
+    d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
+    memcpy(d.bg, sd.background, sizeof(d.bg));
+    // the per-lane traversal stack lives in LDS: depth * 8 B * RT_BLOCK lanes per block
+    if ((size_t)d.stack_depth * RT_BLOCK * sizeof(uint2) > 160 * 1024)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "space partition deeper than the device traversal stack (80 levels)");
+    *out = sc.release();
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* scene) { delete scene; }
+
+extern "C" int rt_scene_tree_info(const rt_scene* scene, rt_tree_info* out) {
+    if (!scene || !out) return RT_ERR_INVALID;
+    *out = scene->tree.info;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_tree_copy(const rt_scene* scene, rt_kd_node* nodes, uint32_t* leaf_refs) {
+    if (!scene) return RT_ERR_INVALID;
+    if (nodes) memcpy(nodes, scene->tree.nodes.data(), scene->tree.nodes.size() * sizeof(rt_kd_node));
+    if (leaf_refs) memcpy(leaf_refs, scene->tree.refs.data(), scene->tree.refs.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+namespace {
+
+int prepare_kernels(rt_context* ctx) {
+    if (ctx->kernels_ready) return RT_OK;
+    RT_HIP(ctx, rt_exact::init_kernels());
+    RT_HIP(ctx, rt_fast::init_kernels());
+    ctx->kernels_ready = true;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                                void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {
+    if (!ctx || !scene || !view || !opt) return fail(ctx, RT_ERR_INVALID, "null argument");
+    if (scene->ctx != ctx) return fail(ctx, RT_ERR_INVALID, "scene belongs to another context");
+    if (view->width == 0 || view->height == 0) return fail(ctx, RT_ERR_INVALID, "empty view");
+    if ((uint64_t)view->width * view->height > 0x7fffffffull / 3) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large");
+    if (opt->max_depth + 2 > RT_MAX_LEVELS) return fail(ctx, RT_ERR_UNSUPPORTED, "max_depth too large");
+    if (opt->fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown fp_mode");
+    const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
+    if (opt->tile_rank >= tile_count) return fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_count");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_kernels(ctx);
+    if (rc != RT_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+
+    const TileGrid grid(view->width, view->height, tile_count);
+    const uint64_t n_slots64 = grid.tiles_of(opt->tile_rank) * 64;
+    if (n_slots64 > 0x7fffffffull) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large");
+    const uint32_t n_slots = (uint32_t)n_slots64;
+
+    FrameArgs A;
+    memset(&A, 0, sizeof(A));
+    A.scene = scene->dev;
+    const Camera cam = camera_basis(*view);
+    memcpy(A.from, view->from, 12);
+    memcpy(A.fwd, cam.forward, 12);
+    memcpy(A.up, cam.up, 12);
+    memcpy(A.right, cam.right, 12);
+    A.hither = view->hither;
+    A.width = view->width;
+    A.height = view->height;
+    A.tiles_x = grid.tiles_x;
+    A.tile_rank = opt->tile_rank;
+    A.tile_count = tile_count;
+    A.n_slots = n_slots;
+    A.max_depth = opt->max_depth;
+    A.min_contribution = opt->min_contribution;
+    A.out_f32 = (float*)d_rgb_f32_out;
+    A.out_u8 = (uint8_t*)d_rgb_u8_out;
+
+    // owned pixels = primary rays
+    uint64_t n_primary = 0;
+    if (tile_count == 1) {
+        n_primary = (uint64_t)view->width * view->height;
+    } else {
+        for (uint64_t lt = 0; lt < grid.tiles_of(opt->tile_rank); ++lt) {
+            const uint64_t t = lt * tile_count + opt->tile_rank;
+            const uint32_t tx = (uint32_t)(t % grid.tiles_x), ty = (uint32_t)(t / grid.tiles_x);
+            const uint32_t w = std::min<uint32_t>(8, view->width - tx * 8), h = std::min<uint32_t>(8, view->height - ty * 8);
+            n_primary += (uint64_t)w * h;
+        }
+    }
+
+    const bool fast = opt->fp_mode == RT_FP_FAST;
+    const bool work = opt->collect_work != 0;
+    size_t cap = std::max<size_t>(ctx->pool_cap, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
+    rt_stats stats;
+    memset(&stats, 0, sizeof(stats));
+
+    for (uint32_t attempt = 0;; ++attempt) {
+        if (cap > 0xfffffff0ull) return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
+        rc = ensure_pool(ctx, cap);
+        if (rc != RT_OK) return rc;
+        A.ray_o = ctx->ray_o.p;
+        A.ray_d = ctx->ray_d.p;
+        A.node_col = ctx->node_col.p;
+        A.node_kid = ctx->node_kid.p;
+        A.pool_cap = (uint32_t)ctx->pool_cap;
+        A.level_count = ctx->levels.p;
+        A.level_base = ctx->levels.p + RT_MAX_LEVELS;
+        A.overflow = ctx->levels.p + 2 * RT_MAX_LEVELS;
+        A.counters = ctx->counters.p;
+
+        RT_HIP(ctx, hipMemsetAsync(ctx->levels.p, 0, (2 * RT_MAX_LEVELS + 1) * sizeof(uint32_t), st));
+        RT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 17 * sizeof(unsigned long long), st));
+        RT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+
+        const uint32_t grid0 = (n_slots + RT_BLOCK - 1) / RT_BLOCK;
+        // Deeper levels' sizes are only known on the device; launch enough blocks for the
+        // largest plausible level and let blocks past the end exit (grid-stride inside).
+        const uint32_t gridn = std::max<uint32_t>(1, std::min<uint32_t>(grid0, 16384));
+        for (uint32_t level = 0; level <= opt->max_depth; ++level) {
+            const uint32_t g = level == 0 ? std::max<uint32_t>(1, grid0) : gridn;
+            RT_HIP(ctx, fast ? rt_fast::launch_trace(A, level, work, g, st) : rt_exact::launch_trace(A, level, work, g, st));
+        }
+        RT_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        for (uint32_t level = opt->max_depth + 1; level-- > 0;) {
+            const uint32_t g = level == 0 ? std::max<uint32_t>(1, grid0) : gridn;
+            RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));
+        }
+        RT_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+        RT_HIP(ctx, hipStreamSynchronize(st));
+
+        uint32_t lv[2 * RT_MAX_LEVELS + 1];
+        RT_HIP(ctx, hipMemcpy(lv, ctx->levels.p, sizeof(lv), hipMemcpyDeviceToHost));
+        if (lv[2 * RT_MAX_LEVELS] != 0) {  // pool overflow: grow and run the frame again
+            uint64_t need = n_slots;
+            for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
+            cap = std::max<size_t>(ctx->pool_cap * 2, (size_t)need + (need >> 2));
+            stats.retries = attempt + 1;
+            if (attempt >= 8) return fail(ctx, RT_ERR_CAPACITY, "ray pool still too small after 8 growth steps");
+            continue;
+        }
+        unsigned long long c[17];
+        RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+        stats.rays_primary = n_primary;
+        stats.rays_shadow = c[1];
+        stats.rays_reflect = c[2];
+        stats.rays_refract = c[3];
+        for (int k = 0; k < 13; ++k) stats.work[k] = c[4 + k];
+        stats.ray_nodes = n_slots;
+        stats.levels = 1;
+        for (uint32_t l = 1; l <= opt->max_depth; ++l) {
+            stats.ray_nodes += lv[l];
+            if (lv[l]) stats.levels = l + 1;
+        }
+        float ms01 = 0, ms12 = 0, ms02 = 0;
+        RT_HIP(ctx, hipEventElapsedTime(&ms01, ctx->ev[0], ctx->ev[1]));
+        RT_HIP(ctx, hipEventElapsedTime(&ms12, ctx->ev[1], ctx->ev[2]));
+        RT_HIP(ctx, hipEventElapsedTime(&ms02, ctx->ev[0], ctx->ev[2]));
+        stats.ms_trace = ms01;
+        stats.ms_resolve = ms12;
+        stats.ms_frame = ms02;
+        break;
+    }
+    if (stats_out) *stats_out = stats;
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                         float* rgb_f32_out, uint8_t* rgb_u8_out, rt_stats* stats_out) {
+    if (!ctx || !view || !opt) return fail(ctx, RT_ERR_INVALID, "null argument");
+    const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
+    if (opt->tile_rank >= tile_count) return fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_count");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t px = tile_count == 1 ? (size_t)view->width * view->height
+                                      : (size_t)rt_tile_pixels(view->width, view->height, opt->tile_rank, tile_count);
+    if (rgb_f32_out && ctx->out_f32.n < px * 3) RT_HIP(ctx, ctx->out_f32.alloc(px * 3));
+    if (rgb_u8_out && ctx->out_u8.n < px * 3) RT_HIP(ctx, ctx->out_u8.alloc(px * 3));
+    // padding slots of edge tiles are never written by the kernels: clear them
+    if (rgb_f32_out && tile_count > 1) RT_HIP(ctx, hipMemset(ctx->out_f32.p, 0, px * 3 * sizeof(float)));
+    if (rgb_u8_out && tile_count > 1) RT_HIP(ctx, hipMemset(ctx->out_u8.p, 0, px * 3));
+    rt_stats stats;
+    int rc = rt_render_device(ctx, scene, view, opt, rgb_f32_out ? ctx->out_f32.p : nullptr,
+                              rgb_u8_out ? ctx->out_u8.p : nullptr, nullptr, &stats);
+    if (rc != RT_OK) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    if (rgb_f32_out) RT_HIP(ctx, hipMemcpy(rgb_f32_out, ctx->out_f32.p, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgb_u8_out) RT_HIP(ctx, hipMemcpy(rgb_u8_out, ctx->out_u8.p, px * 3, hipMemcpyDeviceToHost));
+    stats.ms_d2h = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats_out) *stats_out = stats;
+    return RT_OK;
+}
+
+extern "C" int rt_deinterleave_device(rt_context* ctx, uint32_t width, uint32_t height, uint32_t count,
+                                      uint64_t stride_pixels, uint32_t elem_size, const void* d_gathered,
+                                      void* d_image, void* stream) {
+    if (!ctx || !d_gathered || !d_image) return fail(ctx, RT_ERR_INVALID, "null argument");
+    if (elem_size != 1 && elem_size != 4) return fail(ctx, RT_ERR_INVALID, "elem_size must be 1 or 4");
+    if (width == 0 || height == 0) return fail(ctx, RT_ERR_INVALID, "empty image");
+    const TileGrid g(width, height, count);
+    if (stride_pixels < g.tiles_of(0) * 64) return fail(ctx, RT_ERR_INVALID, "stride_pixels smaller than a rank's tile buffer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    DeinterleaveArgs D;
+    D.width = width; D.height = height; D.tiles_x = g.tiles_x; D.count = g.count; D.elem_size = elem_size;
+    D.stride_pixels = stride_pixels;
+    D.gathered = d_gathered;
+    D.image = d_image;
+    RT_HIP(ctx, rt_exact::launch_deinterleave(D, (hipStream_t)stream));
+    return RT_OK;
+}
+
+extern "C" int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32_t fp_mode, uint64_t n,
+                                  const float* src, const float* ray, const float* near, const uint32_t* ignore,
+                                  uint32_t* out_prim, float* out_dist, float* out_normal) {
+    if (!ctx || !scene || !src || !ray || !near || !ignore || !out_prim || !out_dist || !out_normal)
+        return fail(ctx, RT_ERR_INVALID, "null argument");
+    if (fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown fp_mode");
+    if (n == 0) return RT_OK;
+    for (uint64_t i = 0; i < n; ++i)
+        if (ignore[i] != 0xffffffffu && ignore[i] >= scene->data.primitives.size())
+            return fail(ctx, RT_ERR_INVALID, "ignore index out of range");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_kernels(ctx);
+    if (rc != RT_OK) return rc;
+    DevBuf<float> d_src, d_ray, d_near, d_dist, d_nrm;
+    DevBuf<uint32_t> d_ign, d_prim;
+    RT_HIP(ctx, d_src.alloc(n * 3));
+    RT_HIP(ctx, d_ray.alloc(n * 3));
+    RT_HIP(ctx, d_near.alloc(n));
+    RT_HIP(ctx, d_ign.alloc(n));
+    RT_HIP(ctx, d_prim.alloc(n));
+    RT_HIP(ctx, d_dist.alloc(n));
+    RT_HIP(ctx, d_nrm.alloc(n * 3));
+    RT_HIP(ctx, hipMemcpy(d_src.p, src, n * 12, hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(d_ray.p, ray, n * 12, hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(d_near.p, near, n * 4, hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(d_ign.p, ignore, n * 4, hipMemcpyHostToDevice));
+    if (fp_mode == RT_FP_FAST)
+        RT_HIP(ctx, rt_fast::launch_debug_intersect(scene->dev, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
+    else
+        RT_HIP(ctx, rt_exact::launch_debug_intersect(scene->dev, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    RT_HIP(ctx, hipMemcpy(out_prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(out_dist, d_dist.p, n * 4, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(out_normal, d_nrm.p, n * 12, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_debug_eval(rt_context* ctx, uint32_t op, uint32_t fp_mode, uint64_t n, const float* in,
+                             uint32_t in_stride, float* out, uint32_t out_stride, const rt_vertex* verts,
+                             uint32_t n_verts) {
+    static const uint32_t need_in[10] = {13, 11, 15, 7, 21, 21, 6, 7, 2, 1};
+    static const uint32_t need_out[10] = {1, 5, 5, 5, 3, 3, 3, 3, 1, 1};
+    if (!ctx || !in || !out) return fail(ctx, RT_ERR_INVALID, "null argument");
+    if (op > RT_OP_QUANTIZE || fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown op or fp_mode");
+    if (in_stride < need_in[op] || out_stride < need_out[op]) return fail(ctx, RT_ERR_INVALID, "stride too small for op");
+    if (op == RT_OP_POLYGON && (!verts || n_verts < 3)) return fail(ctx, RT_ERR_INVALID, "polygon needs >= 3 vertices");
+    if (n == 0) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<float> d_in, d_out;
+    DevBuf<float4> d_vp, d_vn;
+    RT_HIP(ctx, d_in.alloc(n * in_stride));
+    RT_HIP(ctx, d_out.alloc(n * out_stride));
+    RT_HIP(ctx, hipMemcpy(d_in.p, in, n * in_stride * 4, hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemset(d_out.p, 0, n * out_stride * 4));
+    std::vector<float4> vp, vn;
+    for (uint32_t k = 0; k < n_verts && verts; ++k) {
+        vp.push_back(f4(verts[k].point, 0.0f));
+        vn.push_back(f4(verts[k].normal, 0.0f));
+    }
+    RT_HIP(ctx, d_vp.upload(vp));
+    RT_HIP(ctx, d_vn.upload(vn));
+    if (fp_mode == RT_FP_FAST)
+        RT_HIP(ctx, rt_fast::launch_debug_eval(op, n, d_in.p, in_stride, d_out.p, out_stride, d_vp.p, d_vn.p, n_verts, nullptr));
+    else
+        RT_HIP(ctx, rt_exact::launch_debug_eval(op, n, d_in.p, in_stride, d_out.p, out_stride, d_vp.p, d_vn.p, n_verts, nullptr));
+    RT_HIP(ctx, hipDeviceSynchronize());
+    RT_HIP(ctx, hipMemcpy(out, d_out.p, n * out_stride * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}

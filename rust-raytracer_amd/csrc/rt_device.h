@@ -1,0 +1,611 @@
+// Device routines of the render path for gfx950 (wave64).  Included by rt_kernels.hip,
+// which is compiled twice into two namespaces:
+//   RT_FAST == 0  ("exact"):  built with -ffp-contract=off; every expression is written in
+//       the reference's operation order with IEEE divide and sqrt, so each routine returns
+//       the bits the reference's scalar f32 code returns (pow excepted: a fixed binary64
+//       sequence replaces libm powf).
+//   RT_FAST == 1  ("fast"):   FMA contraction on, slab test with per-ray reciprocals,
+//       hardware exp2/log2 pow.  Same algorithm, different rounding.
+//
+// Reference functions restated here (file:line relative to the reference tree):
+//   aabb_slab_test      BoundingBox::intersect          src/shape.rs:84-172
+//   isect_sphere        Sphere::intersect               src/sphere.rs:27-79
+//   isect_cone          Cone::intersect                 src/cone.rs:97-221
+//   isect_polygon       Polygon::intersect              src/polygon.rs:58-293
+//   shade_phong         Phong::get_visible_color        src/phong.rs:29-63
+//   shade_blinn_phong   BlinnPhong::get_visible_color   src/blinn_phong.rs:29-57
+//   reflect / refract   Vector::reflected / refracted   src/vector_math.rs:51-73
+//   kd_traverse_closest SpacePartition::intersect       src/space_partition.rs:268-385
+//   quantize_u8         (c * 255.9) as u8               src/ppm.rs:20-22
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_launch.h"
+
+#ifndef RT_FAST
+#error "define RT_FAST to 0 or 1"
+#endif
+
+#define RT_DEV __device__ __forceinline__
+
+namespace RT_NS {
+
+constexpr uint32_t NO_PRIM = 0xffffffffu;
+constexpr uint32_t KIND_SPHERE = 0, KIND_CONE = 1, KIND_POLYGON = 2;
+constexpr uint32_t AXIS_LEAF = 3;
+// Leaves with at least this many entries are walked by the whole wave with scalar loads.
+constexpr uint32_t BIG_LEAF = 24;
+
+// Pointers to read-only scene data are held in the constant address space so that a
+// wave-uniform index turns into scalar (SMEM) loads.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4* cu4_ptr;
+
+struct F3 {
+    float x, y, z;
+};
+
+RT_DEV F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+RT_DEV F3 add(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV F3 sub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT_DEV F3 mul(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+RT_DEV F3 divs(F3 a, float s) { return F3{a.x / s, a.y / s, a.z / s}; }  // three true divisions, src/vector_math.rs:276-305
+RT_DEV F3 neg(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+RT_DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // src/vector_math.rs:436-438
+RT_DEV F3 cross(F3 a, F3 b) {                                                // src/vector_math.rs:428-434
+    return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+RT_DEV float magnitude(F3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }  // src/vector_math.rs:25-28
+RT_DEV F3 normalized(F3 a) { return divs(a, magnitude(a)); }                       // src/vector_math.rs:35-38
+RT_DEV float comp(F3 a, uint32_t axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
+RT_DEV F3 from4(float4 v) { return F3{v.x, v.y, v.z}; }
+
+// src/vector_math.rs:440-448 (normalises its result)
+RT_DEV F3 interpolate(F3 v1, F3 v2, float s) {
+    F3 r{v1.x * s + v2.x * (1.0f - s), v1.y * s + v2.y * (1.0f - s), v1.z * s + v2.z * (1.0f - s)};
+    return divs(r, magnitude(r));
+}
+
+// src/vector_math.rs:51-53
+RT_DEV F3 reflect(F3 v, F3 n) {
+    float k = 2.0f * dot(v, n);
+    return sub(v, mul(n, k));
+}
+
+// src/vector_math.rs:62-73 (total internal reflection falls back to reflect)
+RT_DEV F3 refract(F3 v, F3 n, float ri) {
+    float dp = dot(v, n);
+    float a = 1.0f - ((1.0f - dp * dp) / (ri * ri));
+    if (a >= 0.0f) {
+        float b = sqrtf(a) + dp / ri;
+        return sub(divs(v, ri), mul(n, b));
+    }
+    return reflect(v, n);
+}
+
+// ---------------------------------------------------------------------------------------
+// pow.  Exact build: a fixed sequence of binary64 + - * / and integer bit operations
+// (log2 by atanh series, 2^t by Taylor series); the CPU oracle's "portable pow" is the same
+// sequence, so both produce the same bits.  Fast build: exp2(y * log2(x)) in hardware.
+// ---------------------------------------------------------------------------------------
+RT_DEV float pow_pos(float xf, float yf) {
+#if RT_FAST
+    return __builtin_amdgcn_exp2f(yf * __builtin_amdgcn_logf(xf));
+#else
+    if (!(xf > 0.0f && xf <= 3.402823466e+38f)) return powf(xf, yf);
+    double x = (double)xf, y = (double)yf;
+    unsigned long long ux = (unsigned long long)__double_as_longlong(x);
+    long long e = (long long)((ux >> 52) & 0x7ff) - 1023;
+    unsigned long long mant = ux & 0x000fffffffffffffull;
+    double m = __longlong_as_double((long long)(mant | 0x3ff0000000000000ull));
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double s2 = s * s;
+    double p = 1.0 / 23.0;
+    p = p * s2 + 1.0 / 21.0;
+    p = p * s2 + 1.0 / 19.0;
+    p = p * s2 + 1.0 / 17.0;
+    p = p * s2 + 1.0 / 15.0;
+    p = p * s2 + 1.0 / 13.0;
+    p = p * s2 + 1.0 / 11.0;
+    p = p * s2 + 1.0 / 9.0;
+    p = p * s2 + 1.0 / 7.0;
+    p = p * s2 + 1.0 / 5.0;
+    p = p * s2 + 1.0 / 3.0;
+    p = p * s2 + 1.0;
+    double lnm = 2.0 * s * p;
+    double l2 = (double)e + lnm * 1.4426950408889634;
+    double t = y * l2;
+    if (t > 200.0) t = 200.0;
+    if (t < -200.0) t = -200.0;
+    if (t != t) return (float)t;
+    int ki = (int)(t + (t >= 0.0 ? 0.5 : -0.5));
+    double kd = (double)ki;
+    double f = (t - kd) * 0.6931471805599453;
+    double q = 1.0 / 6227020800.0;
+    q = q * f + 1.0 / 479001600.0;
+    q = q * f + 1.0 / 39916800.0;
+    q = q * f + 1.0 / 3628800.0;
+    q = q * f + 1.0 / 362880.0;
+    q = q * f + 1.0 / 40320.0;
+    q = q * f + 1.0 / 5040.0;
+    q = q * f + 1.0 / 720.0;
+    q = q * f + 1.0 / 120.0;
+    q = q * f + 1.0 / 24.0;
+    q = q * f + 1.0 / 6.0;
+    q = q * f + 0.5;
+    q = q * f + 1.0;
+    q = q * f + 1.0;
+    double sc = __longlong_as_double((long long)(ki + 1023) << 52);
+    return (float)(q * sc);
+#endif
+}
+
+// src/ppm.rs:20-22: Rust's `as u8` truncates, saturates and sends NaN to 0.
+RT_DEV uint32_t quantize_u8(float c) {
+    float v = c * 255.9f;
+    if (!(v == v)) return 0u;
+    if (v <= 0.0f) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (uint32_t)v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Surfaces
+// ---------------------------------------------------------------------------------------
+struct Surface {
+    F3 color;
+    float kd, ks, shine, reflectance, transmittance, ior;
+    uint32_t model;
+};
+
+// src/phong.rs:29-63.  `view` is the incoming ray direction (src/scene.rs:121).
+RT_DEV F3 shade_phong(const Surface& s, F3 normal, F3 view, F3 ldir, F3 lcol) {
+    float ndv = dot(normal, view);
+    if (ndv > 0.0f) return f3(0.0f, 0.0f, 0.0f);
+    F3 rv = sub(view, mul(normal, 2.0f * ndv));
+    float spec = 0.0f;
+    float ldr = dot(rv, ldir);
+    if (ldr > 0.0f) spec = s.ks * pow_pos(ldr, s.shine);
+    float diff = 0.0f;
+    float ndl = dot(normal, ldir);
+    if (ndl > 0.0f) diff = s.kd * ndl;
+    return F3{lcol.x * (spec + diff * s.color.x), lcol.y * (spec + diff * s.color.y), lcol.z * (spec + diff * s.color.z)};
+}
+
+// src/blinn_phong.rs:29-57 (no back-face early-out)
+RT_DEV F3 shade_blinn_phong(const Surface& s, F3 normal, F3 view, F3 ldir, F3 lcol) {
+    F3 half = normalized(sub(ldir, view));
+    float spec = 0.0f;
+    float ndh = dot(normal, half);
+    if (ndh > 0.0f) spec = s.ks * pow_pos(ndh, s.shine);
+    float diff = 0.0f;
+    float ndl = dot(normal, ldir);
+    if (ndl > 0.0f) diff = s.kd * ndl;
+    return F3{lcol.x * (spec + diff * s.color.x), lcol.y * (spec + diff * s.color.y), lcol.z * (spec + diff * s.color.z)};
+}
+
+// ---------------------------------------------------------------------------------------
+// Axis-aligned box slab test, src/shape.rs:84-172.  bmax is fl(corner + extent).
+// ---------------------------------------------------------------------------------------
+struct RayInv {  // fast build only: per-ray reciprocals of the direction
+    F3 inv;
+};
+
+RT_DEV bool aabb_slab_test(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, const RayInv& ri) {
+    float largest_near = -3.402823466e+38f;  // std::f32::MIN
+    float smallest_far = 3.402823466e+38f;
+    (void)ri;
+    F3 to_min = sub(bmin, src);
+    F3 to_max = sub(bmax, src);
+
+    if (ray.x != 0.0f) {
+#if RT_FAST
+        float a = to_min.x * ri.inv.x, b = to_max.x * ri.inv.x;
+#else
+        float a = to_min.x / ray.x, b = to_max.x / ray.x;
+#endif
+        if (a < b) { largest_near = a; smallest_far = b; }
+        else       { largest_near = b; smallest_far = a; }
+    } else if (src.x < bmin.x || src.x > bmax.x) {
+        return false;
+    }
+    if (ray.y != 0.0f) {
+#if RT_FAST
+        float a = to_min.y * ri.inv.y, b = to_max.y * ri.inv.y;
+#else
+        float a = to_min.y / ray.y, b = to_max.y / ray.y;
+#endif
+        float nr, fr;
+        if (a < b) { nr = a; fr = b; } else { nr = b; fr = a; }
+        if (nr > largest_near) largest_near = nr;
+        if (fr < smallest_far) smallest_far = fr;
+    } else if (src.y < bmin.y || src.y > bmax.y) {
+        return false;
+    }
+    if (ray.z != 0.0f) {
+#if RT_FAST
+        float a = to_min.z * ri.inv.z, b = to_max.z * ri.inv.z;
+#else
+        float a = to_min.z / ray.z, b = to_max.z / ray.z;
+#endif
+        float nr, fr;
+        if (a < b) { nr = a; fr = b; } else { nr = b; fr = a; }
+        if (nr > largest_near) largest_near = nr;
+        if (fr < smallest_far) smallest_far = fr;
+    } else if (src.z < bmin.z || src.z > bmax.z) {
+        return false;
+    }
+    return smallest_far >= largest_near && smallest_far >= near_cull;
+}
+
+// ---------------------------------------------------------------------------------------
+// Sphere, src/sphere.rs:27-79.  The distance and the normal are split so that the normal
+// is only formed for a hit that becomes the leaf's nearest.
+// ---------------------------------------------------------------------------------------
+RT_DEV bool isect_sphere(F3 c, float r, F3 src, F3 ray, float near, float& t_out) {
+    F3 sc = sub(src, c);
+    float a = dot(ray, ray);
+    float b = 2.0f * dot(ray, sc);
+    float cc = dot(sc, sc) - r * r;
+    float disc = b * b - 4.0f * a * cc;
+    if (disc >= 0.0f) {
+        float sq = sqrtf(disc);
+        float t = (-b - sq) / (2.0f * a);
+        if (t < near) t = (-b + sq) / (2.0f * a);
+        if (t >= near) { t_out = t; return true; }
+    }
+    return false;
+}
+RT_DEV F3 sphere_normal(F3 c, F3 src, F3 ray, float t) { return normalized(sub(add(src, mul(ray, t)), c)); }
+
+// ---------------------------------------------------------------------------------------
+// Cone / cylinder / frustum without caps, src/cone.rs:97-221
+// ---------------------------------------------------------------------------------------
+RT_DEV bool isect_cone(F3 base, float br, F3 apex, float ar, F3 src, F3 ray, float near, float& t_out, F3& n_out) {
+    F3 base_to_apex = sub(apex, base);
+    F3 w = normalized(base_to_apex);
+    F3 e;
+    if (fabsf(w.x) < fabsf(w.y) && fabsf(w.x) < fabsf(w.z)) e = f3(1.0f, 0.0f, 0.0f);
+    else if (fabsf(w.y) < fabsf(w.z)) e = f3(0.0f, 1.0f, 0.0f);
+    else e = f3(0.0f, 0.0f, 1.0f);
+    F3 u = cross(w, e);
+    F3 v = cross(w, u);
+
+    F3 base_to_src = sub(src, base);
+    F3 S{dot(base_to_src, u), dot(base_to_src, v), dot(base_to_src, w)};
+    F3 R{dot(ray, u), dot(ray, v), dot(ray, w)};
+
+    float mag = magnitude(base_to_apex);
+    float dr = br - ar;
+
+    float a = R.x * R.x + R.y * R.y - dr * dr * R.z * R.z / (mag * mag);
+    float b = 2.0f * S.x * R.x + 2.0f * S.y * R.y - 2.0f * dr * dr * S.z * R.z / (mag * mag) +
+              2.0f * br * dr * R.z / mag;
+    float c = S.x * S.x + S.y * S.y - br * br - dr * dr * S.z * S.z / (mag * mag) + 2.0f * br * dr * S.z / mag;
+
+    float disc = b * b - 4.0f * a * c;
+    if (disc >= 0.0f) {
+        float sq = sqrtf(disc);
+        float r1 = (-b - sq) / (2.0f * a);
+        float r2 = (-b + sq) / (2.0f * a);
+        float w1 = r1 * R.z + S.z;
+        float w2 = r2 * R.z + S.z;
+        float result;
+        if (r1 < r2 && r1 >= near && w1 >= 0.0f && w1 <= mag) result = r1;
+        else if (r2 >= near && w2 >= 0.0f && w2 <= mag) result = r2;
+        else result = -1.0f;
+        if (result >= near) {
+            F3 nu{(result * R.x + S.x) * mag, (result * R.y + S.y) * mag, dr};
+            F3 n{nu.x * u.x + nu.y * v.x + nu.z * w.x, nu.x * u.y + nu.y * v.y + nu.z * w.y,
+                 nu.x * u.z + nu.y * v.z + nu.z * w.z};
+            n_out = normalized(n);
+            t_out = result;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// Polygon with per-vertex normals, src/polygon.rs:58-293.  The reference's three copies of
+// the edge loop (:109-164, :165-210, :211-257) differ only in which coordinate parametrises
+// an edge (`minor`) and which one the crossing ray runs along (`major`).
+// vpos / vnrm hold one float4 per vertex.
+// ---------------------------------------------------------------------------------------
+template <class Ctr>
+RT_DEV bool isect_polygon(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
+                          F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
+    const F3 v0 = from4(vpos[first]);
+    const F3 v1 = from4(vpos[first + 1]);
+    const F3 v2 = from4(vpos[first + 2]);
+    F3 gn = cross(sub(v1, v0), sub(v2, v0));
+    float den = dot(ray, gn);
+    if (fabsf(den) < 0.000001f) return false;
+    float num = dot(sub(v0, src), gn);
+    float plane_dist = num / den;
+    if (plane_dist < near) return false;
+
+    F3 in_plane = add(src, mul(ray, plane_dist));
+    uint32_t minor, major;
+    if (fabsf(gn.z) > fabsf(gn.x) && fabsf(gn.z) > fabsf(gn.y)) { minor = 1; major = 0; }
+    else if (fabsf(gn.y) > fabsf(gn.x)) { minor = 2; major = 0; }
+    else { minor = 2; major = 1; }
+    const float ip_minor = comp(in_plane, minor), ip_major = comp(in_plane, major);
+
+    uint32_t count = 0;
+    bool have_fwd = false, have_rev = false;
+    float fwd_dist = 0.0f, rev_dist = 0.0f, fwd_scale = 0.0f, rev_scale = 0.0f;
+    uint32_t fwd_index = 0, rev_index = 0;
+    ctr.poly_edge_loops(1);
+    F3 point = v0;
+    for (uint32_t i = 0; i < n; ++i) {
+        ctr.poly_edges(1);
+        F3 next_point = (i + 1 < n) ? (i == 0 ? v1 : (i == 1 ? v2 : from4(vpos[first + i + 1]))) : v0;
+        F3 edge = sub(point, next_point);
+        float e_minor = comp(edge, minor);
+        float np_minor = comp(next_point, minor);
+        float np_major = comp(next_point, major);
+        float e_major = comp(edge, major);
+        point = next_point;
+        if (fabsf(e_minor) < 0.000001f) continue;
+        float scale = (ip_minor - np_minor) / e_minor;
+        if (scale < 0.0f || scale > 1.0f) continue;
+        float d = scale * e_major + np_major - ip_major;
+        if (d >= 0.0f) {
+            count += 1;
+            if (have_fwd && d < fwd_dist) have_fwd = false;
+            if (!have_fwd) { have_fwd = true; fwd_dist = d; fwd_index = i; fwd_scale = scale; }
+        } else {
+            if (have_rev && d > rev_dist) have_rev = false;
+            if (!have_rev) { have_rev = true; rev_dist = d; rev_index = i; rev_scale = scale; }
+        }
+    }
+    if ((count & 1u) == 0) return false;
+    if (!(have_fwd && have_rev)) return false;
+
+    F3 fna = from4(vnrm[first + fwd_index]);
+    F3 fnb = from4(vnrm[first + (fwd_index + 1 < n ? fwd_index + 1 : 0)]);
+    F3 fwd_normal = normalized(interpolate(fna, fnb, fwd_scale));
+    F3 rna = from4(vnrm[first + rev_index]);
+    F3 rnb = from4(vnrm[first + (rev_index + 1 < n ? rev_index + 1 : 0)]);
+    F3 rev_normal = normalized(interpolate(rna, rnb, rev_scale));
+    float sc = rev_dist / (rev_dist - fwd_dist);
+    n_out = normalized(interpolate(fwd_normal, rev_normal, sc));
+    t_out = plane_dist;
+    return true;
+}
+
+using rtamd::DevScene;
+
+struct NoCounters {
+    RT_DEV void node_visits(uint32_t) {}
+    RT_DEV void interior_steps(uint32_t) {}
+    RT_DEV void sphere_tests(uint32_t) {}
+    RT_DEV void sphere_hits(uint32_t) {}
+    RT_DEV void cone_tests(uint32_t) {}
+    RT_DEV void cone_hits(uint32_t) {}
+    RT_DEV void poly_tests(uint32_t) {}
+    RT_DEV void poly_edge_loops(uint32_t) {}
+    RT_DEV void poly_edges(uint32_t) {}
+    RT_DEV void poly_hits(uint32_t) {}
+    RT_DEV void light_evals(uint32_t) {}
+    RT_DEV void shade_evals(uint32_t) {}
+    RT_DEV void surface_hits(uint32_t) {}
+};
+
+struct WorkCounters {
+    uint32_t c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    RT_DEV void node_visits(uint32_t n) { c[0] += n; }
+    RT_DEV void interior_steps(uint32_t n) { c[1] += n; }
+    RT_DEV void sphere_tests(uint32_t n) { c[2] += n; }
+    RT_DEV void sphere_hits(uint32_t n) { c[3] += n; }
+    RT_DEV void cone_tests(uint32_t n) { c[4] += n; }
+    RT_DEV void cone_hits(uint32_t n) { c[5] += n; }
+    RT_DEV void poly_tests(uint32_t n) { c[6] += n; }
+    RT_DEV void poly_edge_loops(uint32_t n) { c[7] += n; }
+    RT_DEV void poly_edges(uint32_t n) { c[8] += n; }
+    RT_DEV void poly_hits(uint32_t n) { c[9] += n; }
+    RT_DEV void light_evals(uint32_t n) { c[10] += n; }
+    RT_DEV void shade_evals(uint32_t n) { c[11] += n; }
+    RT_DEV void surface_hits(uint32_t n) { c[12] += n; }
+};
+
+struct Hit {
+    float dist;
+    uint32_t prim;
+    F3 n;
+};
+
+// One leaf entry against one ray; updates (have, best) with the reference's strict `<`
+// (src/space_partition.rs:370-381: the first of equal distances wins).
+template <class Ctr>
+RT_DEV void test_leaf_item(const DevScene& S, uint4 head, float4 body, F3 src, F3 ray, float near, uint32_t ignore,
+                           bool& have, Hit& best, Ctr& ctr) {
+    if (head.x == ignore) return;  // src/space_partition.rs:361-366
+    float t;
+    F3 n;
+    if (head.y == KIND_SPHERE) {
+        ctr.sphere_tests(1);
+        F3 c = f3(body.x, body.y, body.z);
+        if (isect_sphere(c, body.w, src, ray, near, t)) {
+            ctr.sphere_hits(1);
+            if (!have || t < best.dist) {
+                have = true;
+                best.dist = t;
+                best.prim = head.x;
+                best.n = sphere_normal(c, src, ray, t);
+            }
+        }
+    } else if (head.y == KIND_CONE) {
+        ctr.cone_tests(1);
+        float4 c0 = S.cones[head.z * 2], c1 = S.cones[head.z * 2 + 1];
+        if (isect_cone(f3(c0.x, c0.y, c0.z), c0.w, f3(c1.x, c1.y, c1.z), c1.w, src, ray, near, t, n)) {
+            ctr.cone_hits(1);
+            if (!have || t < best.dist) { have = true; best.dist = t; best.prim = head.x; best.n = n; }
+        }
+    } else {
+        ctr.poly_tests(1);
+        if (isect_polygon(S.vpos, S.vnrm, head.z, head.w, src, ray, near, t, n, ctr)) {
+            ctr.poly_hits(1);
+            if (!have || t < best.dist) { have = true; best.dist = t; best.prim = head.x; best.n = n; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Closest hit through the flattened partition, src/space_partition.rs:268-385.
+//
+// The reference recursion is:  visit(node) = none if the node's box is missed; the leaf's
+// nearest hit for a leaf; else r = visit(child on src's side of the plane) and, if r is
+// none or r's end point lies strictly beyond the plane, visit(other child) INSTEAD of r.
+// Iterative form: each interior node on the current path whose far child is still
+// unvisited has one stack entry {far child | axis << 30, plane}.  When a subtree finishes
+// with result r, entries are popped: the first one for which r is none or beyond its plane
+// discards r and descends into its far child; if none does, r is the answer.
+//
+// The per-lane stack lives in LDS (`stack`, lane-interleaved: entry k of thread t at
+// stack[k * blockDim.x + t]); the host guarantees S.stack_depth >= tree depth.
+//
+// Leaves with >= BIG_LEAF entries are processed by all lanes that reached the same leaf
+// together, the entry index kept wave-uniform so the entry data comes through scalar loads.
+// ---------------------------------------------------------------------------------------
+template <class Ctr>
+RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
+                                uint2* stack, Ctr& ctr) {
+    RayInv ri;
+#if RT_FAST
+    ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+#endif
+    const uint32_t stride = blockDim.x;
+    uint2* my_stack = stack + threadIdx.x;
+    uint32_t sp = 0;
+    uint32_t cur = 0;
+    bool done = false;
+    bool r_hit = false;
+    Hit r;
+    r.dist = 0.0f; r.prim = NO_PRIM; r.n = f3(0.0f, 0.0f, 0.0f);
+
+    while (!done) {
+        // ---- walk down / up until this lane stands on a leaf whose box it hits, or is finished
+        bool at_leaf = false;
+        uint32_t leaf_first = 0, leaf_count = 0;
+        while (!done && !at_leaf) {
+            const uint4 q0 = S.nodes[cur * 4 + 0];
+            const uint4 q1 = S.nodes[cur * 4 + 1];
+            ctr.node_visits(1);
+            const F3 bmin = f3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            const F3 bmax = f3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+            bool go_up = true;
+            if (aabb_slab_test(bmin, bmax, src, ray, near, ri)) {
+                const uint4 q2 = S.nodes[cur * 4 + 2];
+                const uint32_t axis = q1.w;
+                if (axis == AXIS_LEAF) {
+                    at_leaf = true;
+                    leaf_first = q2.x;
+                    leaf_count = q2.y;
+                    go_up = false;
+                } else {
+                    ctr.interior_steps(1);
+                    const float plane = __uint_as_float(q0.w);
+                    const bool under_first = comp(src, axis) < plane;  // :303
+                    const uint32_t first = under_first ? q2.x : q2.y;
+                    const uint32_t second = under_first ? q2.y : q2.x;
+                    my_stack[sp * stride] = make_uint2(second | (axis << 30), q0.w);
+                    ++sp;
+                    cur = first;
+                    go_up = false;
+                }
+            } else {
+                r_hit = false;  // :276-279
+            }
+            if (go_up) {
+                // unwind with result (r_hit, r)
+                bool resumed = false;
+                while (sp > 0) {
+                    --sp;
+                    const uint2 ent = my_stack[sp * stride];
+                    const uint32_t axis = ent.x >> 30;
+                    const float plane = __uint_as_float(ent.y);
+                    bool take_second = !r_hit;
+                    if (r_hit) {
+                        const float endpoint = comp(src, axis) + comp(ray, axis) * r.dist;  // :316, :334
+                        const bool under_first = comp(src, axis) < plane;
+                        take_second = under_first ? (endpoint > plane) : (endpoint < plane);
+                    }
+                    if (take_second) {
+                        cur = ent.x & 0x3fffffffu;
+                        r_hit = false;
+                        resumed = true;
+                        break;
+                    }
+                }
+                if (!resumed) done = true;
+            }
+        }
+
+        if (at_leaf) {
+            // ---- leaf: nearest hit among its entries, in entry order (:348-385)
+            bool have = false;
+            Hit best;
+            best.dist = 0.0f; best.prim = NO_PRIM; best.n = f3(0.0f, 0.0f, 0.0f);
+            if (leaf_count >= BIG_LEAF) {
+                bool mine_done = false;
+                while (!mine_done) {
+                    const uint32_t uf = __builtin_amdgcn_readfirstlane(leaf_first);
+                    if (leaf_first == uf) {
+                        // (read again inside the branch so the index stays a scalar register)
+                        const uint32_t ufs = __builtin_amdgcn_readfirstlane(leaf_first);
+                        const uint32_t ucs = __builtin_amdgcn_readfirstlane(leaf_count);
+                        cu4_ptr items = (cu4_ptr)(S.leaf_items);
+                        for (uint32_t k = 0; k < ucs; ++k) {
+                            const u32x4 hq = items[(ufs + k) * 2];
+                            const u32x4 bq = items[(ufs + k) * 2 + 1];
+                            const uint4 head = make_uint4(hq.x, hq.y, hq.z, hq.w);
+                            const float4 body = make_float4(__uint_as_float(bq.x), __uint_as_float(bq.y),
+                                                            __uint_as_float(bq.z), __uint_as_float(bq.w));
+                            test_leaf_item(S, head, body, src, ray, near, ignore, have, best, ctr);
+                        }
+                        mine_done = true;
+                    }
+                }
+            } else {
+                for (uint32_t k = 0; k < leaf_count; ++k) {
+                    const uint4 head = S.leaf_items[(leaf_first + k) * 2];
+                    const uint4 bq = S.leaf_items[(leaf_first + k) * 2 + 1];
+                    const float4 body = make_float4(__uint_as_float(bq.x), __uint_as_float(bq.y),
+                                                    __uint_as_float(bq.z), __uint_as_float(bq.w));
+                    test_leaf_item(S, head, body, src, ray, near, ignore, have, best, ctr);
+                }
+            }
+            r_hit = have;
+            r = best;
+            // unwind
+            bool resumed = false;
+            while (sp > 0) {
+                --sp;
+                const uint2 ent = my_stack[sp * stride];
+                const uint32_t axis = ent.x >> 30;
+                const float plane = __uint_as_float(ent.y);
+                bool take_second = !r_hit;
+                if (r_hit) {
+                    const float endpoint = comp(src, axis) + comp(ray, axis) * r.dist;
+                    const bool under_first = comp(src, axis) < plane;
+                    take_second = under_first ? (endpoint > plane) : (endpoint < plane);
+                }
+                if (take_second) {
+                    cur = ent.x & 0x3fffffffu;
+                    r_hit = false;
+                    resumed = true;
+                    break;
+                }
+            }
+            if (!resumed) done = true;
+        }
+    }
+    out = r;
+    return r_hit;
+}
+
+}  // namespace RT_NS

@@ -1,0 +1,65 @@
+// Internal host-side declarations shared by the translation units of librtamd.so.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rtamd.h"
+
+namespace rtamd {
+
+struct HostTree {
+    std::vector<rt_kd_node> nodes;
+    std::vector<uint32_t> refs;
+    rt_tree_info info{};
+};
+
+// kd_build.cpp
+int prim_box(const rt_scene_desc& d, uint32_t prim, float corner[3], float extent[3]);
+int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err);
+
+// Validates counts, pointers and every index in a scene description.
+int validate_desc(const rt_scene_desc& d, std::string& err);
+
+// Owning copy of a scene description.
+struct SceneData {
+    std::vector<rt_sphere> spheres;
+    std::vector<rt_cone> cones;
+    std::vector<rt_polygon> polygons;
+    std::vector<rt_vertex> vertices;
+    std::vector<rt_primitive> primitives;
+    std::vector<rt_surface> surfaces;
+    std::vector<rt_light> lights;
+    float background[3] = {1.0f, 1.0f, 1.0f};  // reference src/scene.rs:26
+    rt_scene_desc desc{};
+    void refresh_desc();  // points desc at the vectors
+    void assign(const rt_scene_desc& d);
+};
+
+// Camera basis (reference src/render.rs:81-92)
+struct Camera {
+    float forward[3], right[3], up[3];
+};
+Camera camera_basis(const rt_view& v);
+
+// tiles.cpp: interleaved 8x8 tiles
+struct TileGrid {
+    uint32_t width, height, tiles_x, tiles_y, count;
+    uint64_t n_tiles;
+    TileGrid(uint32_t w, uint32_t h, uint32_t c)
+        : width(w), height(h), tiles_x((w + 7) / 8), tiles_y((h + 7) / 8), count(c ? c : 1),
+          n_tiles((uint64_t)((w + 7) / 8) * ((h + 7) / 8)) {}
+    uint64_t tiles_of(uint32_t rank) const { return rank < n_tiles % count ? n_tiles / count + 1 : n_tiles / count; }
+};
+
+}  // namespace rtamd
+
+struct rt_parsed_scene {
+    rtamd::SceneData data;
+    rt_view view{};
+    std::vector<std::string> warnings;
+};
+
+struct rt_tree {
+    rtamd::HostTree tree;
+};

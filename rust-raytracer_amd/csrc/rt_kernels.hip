@@ -1,0 +1,444 @@
+// Kernels of the render path (gfx950).  Compiled twice: -DRT_FAST=0 -DRT_NS=rt_exact with
+// -ffp-contract=off, and -DRT_FAST=1 -DRT_NS=rt_fast with contraction on.
+//
+// Frame structure (replaces the recursion of Scene::sub_trace, reference src/scene.rs:82-200):
+// the ray tree is evaluated level by level.  Level 0 holds one ray per pixel slot; the
+// trace kernel of level d intersects each of its rays, does the direct lighting with its
+// shadow rays (src/scene.rs:103-125), and appends the reflection / refraction rays it
+// spawns (src/scene.rs:127-193) to level d+1 using a wave-wide ballot + prefix count and
+// one atomic per wave.  Every ray owns one node in a pool (node index = ray index): the
+// node keeps the direct colour, the two child indices and their weights.  After the last
+// level, resolve kernels run from the deepest level up: total = direct + refl * reflectance
+// + refr * transmittance in that order, clamped per node exactly as src/scene.rs:195 does
+// before the parent multiplies it -- the clamp makes the recursion non-linear, so path
+// throughput accumulation would not reproduce it.
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+#include "rt_launch.h"
+
+namespace RT_NS {
+
+using rtamd::DeinterleaveArgs;
+using rtamd::FrameArgs;
+
+constexpr uint32_t NONE = 0xffffffffu;
+
+RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+RT_DEV uint32_t prefix_count(uint64_t mask) {  // set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+RT_DEV uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+RT_DEV Surface load_surface(const DevScene& S, uint32_t id) {
+    const float4 a = S.surfaces[id * 3 + 0], b = S.surfaces[id * 3 + 1], c = S.surfaces[id * 3 + 2];
+    Surface s;
+    s.color = f3(a.x, a.y, a.z);
+    s.kd = a.w;
+    s.ks = b.x; s.shine = b.y; s.reflectance = b.z; s.transmittance = b.w;
+    s.ior = c.x;
+    s.model = __float_as_uint(c.y);
+    return s;
+}
+
+// Pixel of slot `slot` in this rank's compact tile buffer (8x8 tiles, tile t of the
+// row-major tile grid belongs to rank t % tile_count; local tile = t / tile_count).
+RT_DEV bool slot_to_pixel(const FrameArgs& A, uint32_t slot, uint32_t& x, uint32_t& y) {
+    const uint32_t local_tile = slot >> 6, in_tile = slot & 63u;
+    const uint64_t t = (uint64_t)local_tile * A.tile_count + A.tile_rank;
+    const uint32_t ty = (uint32_t)(t / A.tiles_x), tx = (uint32_t)(t % A.tiles_x);
+    x = tx * 8 + (in_tile & 7u);
+    y = ty * 8 + (in_tile >> 3);
+    return x < A.width && y < A.height;
+}
+
+// Rays of `level` that exist in the pool.  level_count counts every ray the previous level
+// wanted to append; those that did not fit were dropped (and the frame flagged for a
+// re-run with a larger pool), so the level ends where the pool ends.
+RT_DEV uint32_t level_size(const FrameArgs& A, uint32_t level, uint32_t base) {
+    const uint32_t wanted = A.level_count[level];
+    const uint32_t room = base < A.pool_cap ? A.pool_cap - base : 0u;
+    return wanted < room ? wanted : room;
+}
+
+// ---------------------------------------------------------------------------------------
+// trace: one bounce level
+// ---------------------------------------------------------------------------------------
+template <bool LEVEL0, class Ctr>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace(FrameArgs A, uint32_t level) {
+    extern __shared__ uint2 lds_stack[];
+    const DevScene& S = A.scene;
+    const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
+    const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
+    const uint32_t next_base = base + count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = next_base;
+
+    Ctr ctr;
+    uint32_t n_shadow = 0, n_refl = 0, n_refr = 0;
+
+    for (uint32_t chunk = blockIdx.x * RT_BLOCK; chunk < count; chunk += gridDim.x * RT_BLOCK) {
+        const uint32_t i = chunk + threadIdx.x;
+        bool active = i < count;
+        const uint32_t node = base + i;
+
+        F3 src, ray;
+        float near, contribution;
+        uint32_t ignore;
+        if (LEVEL0) {
+            uint32_t px = 0, py = 0;
+            active = active && slot_to_pixel(A, i, px, py);
+            // src/render.rs:101-108
+            const float sy = 1.0f - ((float)(2 * (int)py + 1)) / ((float)A.height);
+            const float sx = -1.0f + ((float)(2 * (int)px + 1)) / ((float)A.width);
+            const F3 fwd = f3(A.fwd[0], A.fwd[1], A.fwd[2]);
+            const F3 up = f3(A.up[0], A.up[1], A.up[2]);
+            const F3 right = f3(A.right[0], A.right[1], A.right[2]);
+            ray = normalized(add(add(fwd, mul(up, sy)), mul(right, sx)));
+            src = f3(A.from[0], A.from[1], A.from[2]);
+            near = A.hither;
+            contribution = 1.0f;
+            ignore = NO_PRIM;
+        } else {
+            const float4 ro = active ? A.ray_o[node] : make_float4(0, 0, 0, 0);
+            const float4 rd = active ? A.ray_d[node] : make_float4(1, 0, 0, 0);
+            src = f3(ro.x, ro.y, ro.z);
+            contribution = ro.w;
+            ray = f3(rd.x, rd.y, rd.z);
+            ignore = __float_as_uint(rd.w);
+            // reflection rays ignore their surface and start at 0; refraction rays ignore
+            // nothing and start at 0.0001 (src/scene.rs:136-137, :186-187)
+            near = ignore == NO_PRIM ? 0.0001f : 0.0f;
+        }
+
+        F3 total = f3(0.0f, 0.0f, 0.0f);
+        bool want_refl = false, want_refr = false, is_hit = false;
+        F3 refl_ray = f3(0, 0, 0), refr_ray = f3(0, 0, 0), pos = f3(0, 0, 0);
+        float reflectance = 0.0f, transmittance = 0.0f, refl_contrib = 0.0f, refr_contrib = 0.0f;
+        uint32_t hit_prim = NO_PRIM;
+
+        if (active) {
+            Hit hit;
+            if (kd_traverse_closest(S, src, ray, near, ignore, hit, lds_stack, ctr)) {
+                is_hit = true;
+                ctr.surface_hits(1);
+                hit_prim = hit.prim;
+                const Surface surf = load_surface(S, S.prim_surface[hit.prim]);
+                const F3 normal = hit.n;
+                pos = add(src, mul(ray, hit.dist));            // src/scene.rs:95
+                const bool back_face = dot(normal, ray) > 0.0f;  // :96
+
+                if (!back_face) {
+                    for (uint32_t l = 0; l < S.n_lights; ++l) {  // :103-125
+                        ctr.light_evals(1);
+                        const float4 lp = S.lights[l * 2], lc = S.lights[l * 2 + 1];
+                        const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
+                        const float ldist = magnitude(to_light);
+                        const F3 ldir = divs(to_light, ldist);
+                        ++n_shadow;
+                        Hit blocker;
+                        bool blocked = false;
+                        if (kd_traverse_closest(S, pos, ldir, 0.0f, hit.prim, blocker, lds_stack, ctr))
+                            blocked = blocker.dist <= ldist;
+                        if (!blocked) {
+                            ctr.shade_evals(1);
+                            const F3 lcol = f3(lc.x, lc.y, lc.z);
+                            const F3 direct = surf.model == 0u ? shade_phong(surf, normal, ray, ldir, lcol)
+                                                               : shade_blinn_phong(surf, normal, ray, ldir, lcol);
+                            total = add(total, direct);
+                        }
+                    }
+                    if (level < A.max_depth) {  // :127-144
+                        refl_contrib = contribution * surf.reflectance;
+                        if (refl_contrib > A.min_contribution) {
+                            want_refl = true;
+                            refl_ray = reflect(ray, normal);
+                            reflectance = surf.reflectance;
+                        }
+                    }
+                }
+                if (level < A.max_depth) {  // :147-193
+                    if (back_face) transmittance = surf.transmittance > A.min_contribution ? 1.0f : 0.0f;
+                    else transmittance = surf.transmittance;
+                    refr_contrib = contribution * transmittance;
+                    if (refr_contrib > A.min_contribution) {
+                        want_refr = true;
+                        refr_ray = back_face ? refract(ray, neg(normal), 1.0f / surf.ior) : refract(ray, normal, surf.ior);
+                    }
+                }
+            } else {
+                total = f3(S.bg[0], S.bg[1], S.bg[2]);  // :199, never clamped
+            }
+        }
+
+        // ---- append the spawned rays to the next level: reflection slots first, then refraction
+        const uint64_t m_refl = __ballot(want_refl);
+        const uint64_t m_refr = __ballot(want_refr);
+        const uint32_t c_refl = (uint32_t)__popcll(m_refl), c_refr = (uint32_t)__popcll(m_refr);
+        uint32_t refl_idx = NONE, refr_idx = NONE;
+        if (c_refl + c_refr) {
+            uint32_t slot0 = 0;
+            if (lane_id() == 0) slot0 = atomicAdd(&A.level_count[level + 1], c_refl + c_refr);
+            slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            if (want_refl) refl_idx = next_base + slot0 + prefix_count(m_refl);
+            if (want_refr) refr_idx = next_base + slot0 + c_refl + prefix_count(m_refr);
+            // The pool is finite: a ray that does not fit is dropped and the frame is flagged
+            // so that the host re-runs it with a larger pool.
+            if (want_refl && refl_idx >= A.pool_cap) { refl_idx = NONE; want_refl = false; *A.overflow = 1u; }
+            if (want_refr && refr_idx >= A.pool_cap) { refr_idx = NONE; want_refr = false; *A.overflow = 1u; }
+        }
+        if (want_refl) {
+            ++n_refl;
+            A.ray_o[refl_idx] = make_float4(pos.x, pos.y, pos.z, refl_contrib);
+            A.ray_d[refl_idx] = make_float4(refl_ray.x, refl_ray.y, refl_ray.z, __uint_as_float(hit_prim));
+        }
+        if (want_refr) {
+            ++n_refr;
+            A.ray_o[refr_idx] = make_float4(pos.x, pos.y, pos.z, refr_contrib);
+            A.ray_d[refr_idx] = make_float4(refr_ray.x, refr_ray.y, refr_ray.z, __uint_as_float(NO_PRIM));
+        }
+        if (active) {
+            if (is_hit && !want_refl && !want_refr) {  // no children: final already (:195)
+                total.x = total.x > 1.0f ? 1.0f : total.x;
+                total.y = total.y > 1.0f ? 1.0f : total.y;
+                total.z = total.z > 1.0f ? 1.0f : total.z;
+            }
+            A.node_col[node] = make_float4(total.x, total.y, total.z, reflectance);
+            A.node_kid[node] = make_uint4(refl_idx, refr_idx, __float_as_uint(transmittance), is_hit ? 1u : 0u);
+        }
+    }
+
+    // ---- counters: one atomic per wave and counter
+    const uint32_t s_shadow = wave_sum(n_shadow), s_refl = wave_sum(n_refl), s_refr = wave_sum(n_refr);
+    if (lane_id() == 0) {
+        if (s_shadow) atomicAdd(&A.counters[1], (unsigned long long)s_shadow);
+        if (s_refl) atomicAdd(&A.counters[2], (unsigned long long)s_refl);
+        if (s_refr) atomicAdd(&A.counters[3], (unsigned long long)s_refr);
+    }
+    if constexpr (sizeof(Ctr) > 4) {
+        for (int k = 0; k < 13; ++k) {
+            const uint32_t s = wave_sum(ctr.c[k]);
+            if (lane_id() == 0 && s) atomicAdd(&A.counters[4 + k], (unsigned long long)s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// resolve: fold the children of one level into their parents; level 0 also writes the
+// framebuffer (f32 as RenderTarget, src/render.rs:50-70; u8 as the PPM writer, src/ppm.rs:20-22)
+// ---------------------------------------------------------------------------------------
+template <bool LEVEL0>
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(FrameArgs A, uint32_t level) {
+    const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
+    const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
+        uint32_t px = 0, py = 0;
+        if (LEVEL0 && !slot_to_pixel(A, i, px, py)) continue;
+        const uint32_t node = base + i;
+        const uint4 kid = A.node_kid[node];
+        float4 col = A.node_col[node];
+        if (kid.x != NONE || kid.y != NONE) {
+            if (kid.x != NONE) {  // total += reflected * reflectance, src/scene.rs:141-142
+                const float4 c = A.node_col[kid.x];
+                col.x += c.x * col.w; col.y += c.y * col.w; col.z += c.z * col.w;
+            }
+            if (kid.y != NONE) {  // total += refracted * transmittance, src/scene.rs:191
+                const float4 c = A.node_col[kid.y];
+                const float t = __uint_as_float(kid.z);
+                col.x += c.x * t; col.y += c.y * t; col.z += c.z * t;
+            }
+            col.x = col.x > 1.0f ? 1.0f : col.x;  // src/scene.rs:195
+            col.y = col.y > 1.0f ? 1.0f : col.y;
+            col.z = col.z > 1.0f ? 1.0f : col.z;
+            if (!LEVEL0) A.node_col[node] = col;
+        }
+        if (LEVEL0) {
+            // whole image: row-major pixel index; tile-interleaved: the compact slot index
+            const uint64_t o = (A.tile_count > 1 ? (uint64_t)i : (uint64_t)py * A.width + px) * 3;
+            if (A.out_f32) { A.out_f32[o] = col.x; A.out_f32[o + 1] = col.y; A.out_f32[o + 2] = col.z; }
+            if (A.out_u8) {
+                A.out_u8[o] = (uint8_t)quantize_u8(col.x);
+                A.out_u8[o + 1] = (uint8_t)quantize_u8(col.y);
+                A.out_u8[o + 2] = (uint8_t)quantize_u8(col.z);
+            }
+        }
+    }
+}
+
+// Gathered compact tile buffers -> row-major image.  One thread per pixel.
+__global__ void __launch_bounds__(RT_BLOCK) k_deinterleave(DeinterleaveArgs D) {
+    const uint64_t p = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (p >= (uint64_t)D.width * D.height) return;
+    const uint32_t x = (uint32_t)(p % D.width), y = (uint32_t)(p / D.width);
+    const uint64_t t = (uint64_t)(y / 8) * D.tiles_x + (x / 8);
+    const uint32_t rank = (uint32_t)(t % D.count);
+    const uint64_t slot = (t / D.count) * 64 + (y % 8) * 8 + (x % 8);
+    const uint64_t s = (rank * D.stride_pixels + slot) * 3, o = p * 3;
+    if (D.elem_size == 1) {
+        const uint8_t* src = (const uint8_t*)D.gathered;
+        uint8_t* dst = (uint8_t*)D.image;
+        dst[o] = src[s]; dst[o + 1] = src[s + 1]; dst[o + 2] = src[s + 2];
+    } else {
+        const float* src = (const float*)D.gathered;
+        float* dst = (float*)D.image;
+        dst[o] = src[s]; dst[o + 1] = src[s + 1]; dst[o + 2] = src[s + 2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// diagnostics: device routines run one row per lane (parity tests)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK) k_debug_intersect(DevScene S, uint64_t n, const float* src, const float* ray,
+                                                              const float* near, const uint32_t* ignore,
+                                                              uint32_t* out_prim, float* out_dist, float* out_normal) {
+    extern __shared__ uint2 lds_stack[];
+    const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    NoCounters ctr;
+    Hit hit;
+    const bool ok = kd_traverse_closest(S, f3(src[3 * i], src[3 * i + 1], src[3 * i + 2]),
+                                        f3(ray[3 * i], ray[3 * i + 1], ray[3 * i + 2]), near[i], ignore[i], hit,
+                                        lds_stack, ctr);
+    out_prim[i] = ok ? hit.prim : NO_PRIM;
+    out_dist[i] = ok ? hit.dist : 0.0f;
+    out_normal[3 * i] = ok ? hit.n.x : 0.0f;
+    out_normal[3 * i + 1] = ok ? hit.n.y : 0.0f;
+    out_normal[3 * i + 2] = ok ? hit.n.z : 0.0f;
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n, const float* in, uint32_t is,
+                                                         float* out, uint32_t os, const float4* vpos,
+                                                         const float4* vnrm, uint32_t n_verts) {
+    const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + i * is;
+    float* o = out + i * os;
+    NoCounters ctr;
+    RayInv ri;
+    float t = 0.0f;
+    F3 nn = f3(0, 0, 0);
+    bool ok = false;
+    switch (op) {
+        case 0: {  // RT_OP_AABB: corner, extent, src, ray, near
+            const F3 bmin = f3(a[0], a[1], a[2]);
+            const F3 bmax = f3(a[0] + a[3], a[1] + a[4], a[2] + a[5]);
+            const F3 ray = f3(a[9], a[10], a[11]);
+#if RT_FAST
+            ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+#endif
+            o[0] = aabb_slab_test(bmin, bmax, f3(a[6], a[7], a[8]), ray, a[12], ri) ? 1.0f : 0.0f;
+            return;
+        }
+        case 1: {  // RT_OP_SPHERE
+            const F3 c = f3(a[0], a[1], a[2]), src = f3(a[4], a[5], a[6]), ray = f3(a[7], a[8], a[9]);
+            ok = isect_sphere(c, a[3], src, ray, a[10], t);
+            if (ok) nn = sphere_normal(c, src, ray, t);
+            break;
+        }
+        case 2:  // RT_OP_CONE
+            ok = isect_cone(f3(a[0], a[1], a[2]), a[3], f3(a[4], a[5], a[6]), a[7], f3(a[8], a[9], a[10]),
+                            f3(a[11], a[12], a[13]), a[14], t, nn);
+            break;
+        case 3:  // RT_OP_POLYGON
+            ok = isect_polygon(vpos, vnrm, 0u, n_verts, f3(a[0], a[1], a[2]), f3(a[3], a[4], a[5]), a[6], t, nn, ctr);
+            break;
+        case 4:
+        case 5: {  // RT_OP_PHONG / RT_OP_BLINN: surface9, n, v, l, lc
+            Surface s;
+            s.color = f3(a[0], a[1], a[2]);
+            s.kd = a[3]; s.ks = a[4]; s.shine = a[5]; s.reflectance = a[6]; s.transmittance = a[7]; s.ior = a[8];
+            s.model = op == 4 ? 0u : 1u;
+            const F3 nrm = f3(a[9], a[10], a[11]), v = f3(a[12], a[13], a[14]), l = f3(a[15], a[16], a[17]),
+                     lc = f3(a[18], a[19], a[20]);
+            const F3 c = op == 4 ? shade_phong(s, nrm, v, l, lc) : shade_blinn_phong(s, nrm, v, l, lc);
+            o[0] = c.x; o[1] = c.y; o[2] = c.z;
+            return;
+        }
+        case 6: {  // RT_OP_REFLECT
+            const F3 r = reflect(f3(a[0], a[1], a[2]), f3(a[3], a[4], a[5]));
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            return;
+        }
+        case 7: {  // RT_OP_REFRACT
+            const F3 r = refract(f3(a[0], a[1], a[2]), f3(a[3], a[4], a[5]), a[6]);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            return;
+        }
+        case 8:  // RT_OP_POW
+            o[0] = pow_pos(a[0], a[1]);
+            return;
+        case 9:  // RT_OP_QUANTIZE
+            o[0] = (float)quantize_u8(a[0]);
+            return;
+        default:
+            return;
+    }
+    o[0] = ok ? 1.0f : 0.0f;
+    o[1] = ok ? t : 0.0f;
+    o[2] = ok ? nn.x : 0.0f;
+    o[3] = ok ? nn.y : 0.0f;
+    o[4] = ok ? nn.z : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-callable launchers (one set per namespace)
+// ---------------------------------------------------------------------------------------
+static size_t stack_bytes(const DevScene& S) { return (size_t)S.stack_depth * RT_BLOCK * sizeof(uint2); }
+
+// Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
+hipError_t init_kernels() {
+    const int max_lds = 160 * 1024;
+    const void* fns[] = {(const void*)k_trace<true, WorkCounters>, (const void*)k_trace<true, NoCounters>,
+                         (const void*)k_trace<false, WorkCounters>, (const void*)k_trace<false, NoCounters>,
+                         (const void*)k_debug_intersect};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_trace(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
+    const size_t lds = stack_bytes(A.scene);
+    if (level == 0) {
+        if (work) hipLaunchKernelGGL((k_trace<true, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        else hipLaunchKernelGGL((k_trace<true, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+    } else {
+        if (work) hipLaunchKernelGGL((k_trace<false, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        else hipLaunchKernelGGL((k_trace<false, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st) {
+    if (level == 0) hipLaunchKernelGGL((k_resolve<true>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+    else hipLaunchKernelGGL((k_resolve<false>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave(const DeinterleaveArgs& D, hipStream_t st) {
+    const uint64_t n = (uint64_t)D.width * D.height;
+    hipLaunchKernelGGL(k_deinterleave, dim3((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, st, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_intersect(const DevScene& S, uint64_t n, const float* src, const float* ray, const float* near,
+                                  const uint32_t* ignore, uint32_t* out_prim, float* out_dist, float* out_normal,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_intersect, dim3((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK),
+                       stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_eval(uint32_t op, uint64_t n, const float* in, uint32_t is, float* out, uint32_t os,
+                             const float4* vpos, const float4* vnrm, uint32_t n_verts, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_eval, dim3((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, st, op, n, in,
+                       is, out, os, vpos, vnrm, n_verts);
+    return hipGetLastError();
+}
+
+}  // namespace RT_NS

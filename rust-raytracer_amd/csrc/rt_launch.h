@@ -1,0 +1,77 @@
+// Plain argument structs shared by the host API and the kernels, and the launcher
+// prototypes of the two kernel builds (namespaces rt_exact and rt_fast).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_BLOCK 256
+#define RT_MAX_LEVELS 64  // max_depth + 2 must fit
+
+namespace rtamd {
+
+// Scene as the kernels see it (all device pointers).
+struct DevScene {
+    const uint4* nodes;        // 4 x uint4 per node: {bmin, plane} {bmax, axis} {under, over, parent, depth} {extent, -}
+    const uint4* leaf_items;   // 2 x uint4 per leaf entry: {prim, kind, pool index | first vertex, n vertices} {sphere: center, radius}
+    const float4* cones;       // 2 per cone: {base, base radius} {apex, apex radius}
+    const float4* vpos;        // per vertex {point, 0}
+    const float4* vnrm;        // per vertex {normal, 0}
+    const float4* surfaces;    // 3 per surface: {color, kd} {ks, shine, reflectance, transmittance} {ior, model bits, -, -}
+    const uint32_t* prim_surface;
+    const float4* lights;      // 2 per light: {position, 0} {color, 0}
+    uint32_t n_lights;
+    uint32_t stack_depth;      // entries per lane in the traversal stack (>= tree depth, >= 1)
+    float bg[3];
+};
+
+struct FrameArgs {
+    DevScene scene;
+    // camera (reference src/render.rs:81-92), computed on the host
+    float from[3], fwd[3], up[3], right[3];
+    float hither;
+    uint32_t width, height;
+    // interleaved tiles
+    uint32_t tiles_x, tile_rank, tile_count;
+    uint32_t n_slots;  // level-0 rays: 64 per local tile
+    // integrator constants (reference src/scene.rs:8-9)
+    uint32_t max_depth;
+    float min_contribution;
+    // ray / node pool: index = level_base[level] + position in level
+    float4* ray_o;     // origin.xyz, contribution
+    float4* ray_d;     // direction.xyz, bits(ignore primitive)
+    float4* node_col;  // direct (later total) colour, reflectance weight
+    uint4* node_kid;   // reflection child, refraction child, bits(transmittance weight), hit flag
+    uint32_t pool_cap;
+    uint32_t* level_count;  // [RT_MAX_LEVELS]
+    uint32_t* level_base;   // [RT_MAX_LEVELS]
+    uint32_t* overflow;
+    unsigned long long* counters;  // [17]: primary, shadow, reflect, refract, then the 13 work counters
+    // outputs (either may be null)
+    float* out_f32;
+    uint8_t* out_u8;
+};
+
+struct DeinterleaveArgs {
+    uint32_t width, height, tiles_x, count, elem_size;
+    uint64_t stride_pixels;
+    const void* gathered;
+    void* image;
+};
+
+}  // namespace rtamd
+
+#define RT_DECLARE_LAUNCHERS(NS)                                                                                     \
+    namespace NS {                                                                                                   \
+    hipError_t init_kernels();                                                                                       \
+    hipError_t launch_trace(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st);    \
+    hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \
+    hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
+    hipError_t launch_debug_intersect(const rtamd::DevScene& S, uint64_t n, const float* src, const float* ray,      \
+                                      const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist, \
+                                      float* out_normal, hipStream_t st);                                            \
+    hipError_t launch_debug_eval(uint32_t op, uint64_t n, const float* in, uint32_t is, float* out, uint32_t os,     \
+                                 const float4* vpos, const float4* vnrm, uint32_t n_verts, hipStream_t st);          \
+    }
+
+RT_DECLARE_LAUNCHERS(rt_exact)
+RT_DECLARE_LAUNCHERS(rt_fast)

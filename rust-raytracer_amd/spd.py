@@ -95,6 +95,7 @@ def tetra(size: int = 6, width: int = 512, height: int = 512) -> str:
                 45, 1.0, (width, height))
     out.append("b 0.078 0.361 0.753")
     out.append("l 1.876066 -18.123936 -5.000422")
+    out.append("l 6 -4 -9 0.6 0.6 0.5")
     out.append("f 1 0.2 0.2 1 0 0 0 0")
     tris = []
 
