@@ -66,7 +66,9 @@ struct rt_scene {
     rt_context* ctx = nullptr;
     SceneData data;
     HostTree tree;
-    DevBuf<uint4> nodes, leaf_items;
+    DevBuf<uint4> nodes, cone_items, poly_items;
+    DevBuf<float4> sph;
+    DevBuf<uint2> sph_id;
     DevBuf<float4> cones, vpos, vnrm, surfaces, lights;
     DevBuf<uint32_t> prim_surface;
     DevScene dev{};
@@ -175,27 +177,44 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     }
 
     const SceneData& sd = sc->data;
-    // leaf entries, in the builder's list order (src/space_partition.rs:348-385 walks them in order)
-    std::vector<uint4> items(sc->tree.refs.size() * 2);
-    for (size_t k = 0; k < sc->tree.refs.size(); ++k) {
-        const uint32_t prim = sc->tree.refs[k];
-        const rt_primitive& p = sd.primitives[prim];
-        uint4 head = make_uint4(prim, p.kind, p.index, 0);
-        uint4 body = make_uint4(0, 0, 0, 0);
-        if (p.kind == RT_KIND_SPHERE) {
-            const rt_sphere& s = sd.spheres[p.index];
-            memcpy(&body.x, s.center, 12);
-            memcpy(&body.w, &s.radius, 4);
-        } else if (p.kind == RT_KIND_POLYGON) {
-            head.z = sd.polygons[p.index].first_vertex;
-            head.w = sd.polygons[p.index].vertex_count;
-        }
-        items[2 * k] = head;
-        items[2 * k + 1] = body;
-    }
-    std::vector<uint4> nodes(sc->tree.nodes.size() * 4);
+    // Device nodes + leaf runs.  A leaf's list (src/space_partition.rs:348-385 walks it in order)
+    // becomes one run per primitive kind, each in list order with the list position attached.
     static_assert(sizeof(rt_kd_node) == 64, "node layout");
+    std::vector<uint4> nodes(sc->tree.nodes.size() * 4);
     memcpy(nodes.data(), sc->tree.nodes.data(), sc->tree.nodes.size() * sizeof(rt_kd_node));
+    std::vector<float4> sph;
+    std::vector<uint2> sph_id;
+    std::vector<uint4> cone_items, poly_items;
+    for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
+        const rt_kd_node& n = sc->tree.nodes[ni];
+        if (n.axis != 3) {
+            nodes[ni * 4 + 2] = make_uint4(n.under, n.over, 0, 0);
+            nodes[ni * 4 + 3] = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        const uint32_t s0 = (uint32_t)sph.size(), c0 = (uint32_t)cone_items.size(), p0 = (uint32_t)poly_items.size();
+        uint32_t ns = 0;
+        for (uint32_t k = 0; k < n.over; ++k) {
+            const uint32_t prim = sc->tree.refs[n.under + k];
+            const rt_primitive& p = sd.primitives[prim];
+            if (p.kind == RT_KIND_SPHERE) {
+                const rt_sphere& s = sd.spheres[p.index];
+                sph.push_back(make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius));  // src/sphere.rs:53
+                sph_id.push_back(make_uint2(prim, k));
+                ++ns;
+            } else if (p.kind == RT_KIND_CONE) {
+                cone_items.push_back(make_uint4(prim, k, p.index, 0));
+            } else {
+                poly_items.push_back(make_uint4(prim, k, sd.polygons[p.index].first_vertex, sd.polygons[p.index].vertex_count));
+            }
+        }
+        while (sph.size() % 4) {  // pad: the sphere loop reads entries four at a time (and skips k >= count)
+            sph.push_back(make_float4(0.0f, 0.0f, 0.0f, -1.0f));
+            sph_id.push_back(make_uint2(0xffffffffu, 0xffffffffu));
+        }
+        nodes[ni * 4 + 2] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
+        nodes[ni * 4 + 3] = make_uint4(p0, (uint32_t)poly_items.size() - p0, 0, 0);
+    }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;
     for (const rt_cone& c : sd.cones) {
@@ -219,7 +238,10 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     for (const rt_primitive& p : sd.primitives) prim_surface.push_back(p.surface);
 
     RT_HIP(ctx, sc->nodes.upload(nodes));
-    RT_HIP(ctx, sc->leaf_items.upload(items));
+    RT_HIP(ctx, sc->sph.upload(sph));
+    RT_HIP(ctx, sc->sph_id.upload(sph_id));
+    RT_HIP(ctx, sc->cone_items.upload(cone_items));
+    RT_HIP(ctx, sc->poly_items.upload(poly_items));
     RT_HIP(ctx, sc->cones.upload(cones));
     RT_HIP(ctx, sc->vpos.upload(vpos));
     RT_HIP(ctx, sc->vnrm.upload(vnrm));
@@ -229,7 +251,10 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
 
     DevScene& d = sc->dev;
     d.nodes = sc->nodes.p;
-    d.leaf_items = sc->leaf_items.p;
+    d.sph = sc->sph.p;
+    d.sph_id = sc->sph_id.p;
+    d.cone_items = sc->cone_items.p;
+    d.poly_items = sc->poly_items.p;
     d.cones = sc->cones.p;
     d.vpos = sc->vpos.p;
     d.vnrm = sc->vnrm.p;

@@ -14,7 +14,7 @@
 // throughput accumulation would not reproduce it.
 #include <hip/hip_runtime.h>
 
-#include "rt_device.h"
+#include "rt_traverse.h"
 #include "rt_launch.h"
 
 namespace RT_NS {

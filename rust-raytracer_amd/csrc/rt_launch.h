@@ -11,8 +11,14 @@ namespace rtamd {
 
 // Scene as the kernels see it (all device pointers).
 struct DevScene {
-    const uint4* nodes;        // 4 x uint4 per node: {bmin, plane} {bmax, axis} {under, over, parent, depth} {extent, -}
-    const uint4* leaf_items;   // 2 x uint4 per leaf entry: {prim, kind, pool index | first vertex, n vertices} {sphere: center, radius}
+    // 4 x uint4 per node (64 B): {bmin, plane} {bmax, axis}; interior: {under, over, -, -} {-};
+    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, -, -}
+    const uint4* nodes;
+    // Leaf primitive lists, one run per kind and leaf, each in the builder's list order.
+    const float4* sph;         // sphere runs: {centre, r*r}; every run padded to a multiple of 4 entries
+    const uint2* sph_id;       // parallel to sph: {primitive, position in the leaf's list}
+    const uint4* cone_items;   // {primitive, position in the leaf's list, cone index, -}
+    const uint4* poly_items;   // {primitive, position in the leaf's list, first vertex, vertex count}
     const float4* cones;       // 2 per cone: {base, base radius} {apex, apex radius}
     const float4* vpos;        // per vertex {point, 0}
     const float4* vnrm;        // per vertex {normal, 0}

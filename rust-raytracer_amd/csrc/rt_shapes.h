@@ -1,4 +1,5 @@
-// Device routines of the render path for gfx950 (wave64).  Included by rt_kernels.hip,
+// Device routines of the render path for gfx950 (wave64): vector math, shapes, shading.
+// Included (through rt_traverse.h) by rt_kernels.hip,
 // which is compiled twice into two namespaces:
 //   RT_FAST == 0  ("exact"):  built with -ffp-contract=off; every expression is written in
 //       the reference's operation order with IEEE divide and sqrt, so each routine returns
@@ -380,6 +381,7 @@ RT_DEV bool isect_polygon(const float4* __restrict__ vpos, const float4* __restr
 using rtamd::DevScene;
 
 struct NoCounters {
+    static constexpr bool kEnabled = false;
     RT_DEV void node_visits(uint32_t) {}
     RT_DEV void interior_steps(uint32_t) {}
     RT_DEV void sphere_tests(uint32_t) {}
@@ -396,6 +398,7 @@ struct NoCounters {
 };
 
 struct WorkCounters {
+    static constexpr bool kEnabled = true;
     uint32_t c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RT_DEV void node_visits(uint32_t n) { c[0] += n; }
     RT_DEV void interior_steps(uint32_t n) { c[1] += n; }
@@ -411,201 +414,5 @@ struct WorkCounters {
     RT_DEV void shade_evals(uint32_t n) { c[11] += n; }
     RT_DEV void surface_hits(uint32_t n) { c[12] += n; }
 };
-
-struct Hit {
-    float dist;
-    uint32_t prim;
-    F3 n;
-};
-
-// One leaf entry against one ray; updates (have, best) with the reference's strict `<`
-// (src/space_partition.rs:370-381: the first of equal distances wins).
-template <class Ctr>
-RT_DEV void test_leaf_item(const DevScene& S, uint4 head, float4 body, F3 src, F3 ray, float near, uint32_t ignore,
-                           bool& have, Hit& best, Ctr& ctr) {
-    if (head.x == ignore) return;  // src/space_partition.rs:361-366
-    float t;
-    F3 n;
-    if (head.y == KIND_SPHERE) {
-        ctr.sphere_tests(1);
-        F3 c = f3(body.x, body.y, body.z);
-        if (isect_sphere(c, body.w, src, ray, near, t)) {
-            ctr.sphere_hits(1);
-            if (!have || t < best.dist) {
-                have = true;
-                best.dist = t;
-                best.prim = head.x;
-                best.n = sphere_normal(c, src, ray, t);
-            }
-        }
-    } else if (head.y == KIND_CONE) {
-        ctr.cone_tests(1);
-        float4 c0 = S.cones[head.z * 2], c1 = S.cones[head.z * 2 + 1];
-        if (isect_cone(f3(c0.x, c0.y, c0.z), c0.w, f3(c1.x, c1.y, c1.z), c1.w, src, ray, near, t, n)) {
-            ctr.cone_hits(1);
-            if (!have || t < best.dist) { have = true; best.dist = t; best.prim = head.x; best.n = n; }
-        }
-    } else {
-        ctr.poly_tests(1);
-        if (isect_polygon(S.vpos, S.vnrm, head.z, head.w, src, ray, near, t, n, ctr)) {
-            ctr.poly_hits(1);
-            if (!have || t < best.dist) { have = true; best.dist = t; best.prim = head.x; best.n = n; }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Closest hit through the flattened partition, src/space_partition.rs:268-385.
-//
-// The reference recursion is:  visit(node) = none if the node's box is missed; the leaf's
-// nearest hit for a leaf; else r = visit(child on src's side of the plane) and, if r is
-// none or r's end point lies strictly beyond the plane, visit(other child) INSTEAD of r.
-// Iterative form: each interior node on the current path whose far child is still
-// unvisited has one stack entry {far child | axis << 30, plane}.  When a subtree finishes
-// with result r, entries are popped: the first one for which r is none or beyond its plane
-// discards r and descends into its far child; if none does, r is the answer.
-//
-// The per-lane stack lives in LDS (`stack`, lane-interleaved: entry k of thread t at
-// stack[k * blockDim.x + t]); the host guarantees S.stack_depth >= tree depth.
-//
-// Leaves with >= BIG_LEAF entries are processed by all lanes that reached the same leaf
-// together, the entry index kept wave-uniform so the entry data comes through scalar loads.
-// ---------------------------------------------------------------------------------------
-template <class Ctr>
-RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
-                                uint2* stack, Ctr& ctr) {
-    RayInv ri;
-#if RT_FAST
-    ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
-#endif
-    const uint32_t stride = blockDim.x;
-    uint2* my_stack = stack + threadIdx.x;
-    uint32_t sp = 0;
-    uint32_t cur = 0;
-    bool done = false;
-    bool r_hit = false;
-    Hit r;
-    r.dist = 0.0f; r.prim = NO_PRIM; r.n = f3(0.0f, 0.0f, 0.0f);
-
-    while (!done) {
-        // ---- walk down / up until this lane stands on a leaf whose box it hits, or is finished
-        bool at_leaf = false;
-        uint32_t leaf_first = 0, leaf_count = 0;
-        while (!done && !at_leaf) {
-            const uint4 q0 = S.nodes[cur * 4 + 0];
-            const uint4 q1 = S.nodes[cur * 4 + 1];
-            ctr.node_visits(1);
-            const F3 bmin = f3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-            const F3 bmax = f3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
-            bool go_up = true;
-            if (aabb_slab_test(bmin, bmax, src, ray, near, ri)) {
-                const uint4 q2 = S.nodes[cur * 4 + 2];
-                const uint32_t axis = q1.w;
-                if (axis == AXIS_LEAF) {
-                    at_leaf = true;
-                    leaf_first = q2.x;
-                    leaf_count = q2.y;
-                    go_up = false;
-                } else {
-                    ctr.interior_steps(1);
-                    const float plane = __uint_as_float(q0.w);
-                    const bool under_first = comp(src, axis) < plane;  // :303
-                    const uint32_t first = under_first ? q2.x : q2.y;
-                    const uint32_t second = under_first ? q2.y : q2.x;
-                    my_stack[sp * stride] = make_uint2(second | (axis << 30), q0.w);
-                    ++sp;
-                    cur = first;
-                    go_up = false;
-                }
-            } else {
-                r_hit = false;  // :276-279
-            }
-            if (go_up) {
-                // unwind with result (r_hit, r)
-                bool resumed = false;
-                while (sp > 0) {
-                    --sp;
-                    const uint2 ent = my_stack[sp * stride];
-                    const uint32_t axis = ent.x >> 30;
-                    const float plane = __uint_as_float(ent.y);
-                    bool take_second = !r_hit;
-                    if (r_hit) {
-                        const float endpoint = comp(src, axis) + comp(ray, axis) * r.dist;  // :316, :334
-                        const bool under_first = comp(src, axis) < plane;
-                        take_second = under_first ? (endpoint > plane) : (endpoint < plane);
-                    }
-                    if (take_second) {
-                        cur = ent.x & 0x3fffffffu;
-                        r_hit = false;
-                        resumed = true;
-                        break;
-                    }
-                }
-                if (!resumed) done = true;
-            }
-        }
-
-        if (at_leaf) {
-            // ---- leaf: nearest hit among its entries, in entry order (:348-385)
-            bool have = false;
-            Hit best;
-            best.dist = 0.0f; best.prim = NO_PRIM; best.n = f3(0.0f, 0.0f, 0.0f);
-            if (leaf_count >= BIG_LEAF) {
-                bool mine_done = false;
-                while (!mine_done) {
-                    const uint32_t uf = __builtin_amdgcn_readfirstlane(leaf_first);
-                    if (leaf_first == uf) {
-                        // (read again inside the branch so the index stays a scalar register)
-                        const uint32_t ufs = __builtin_amdgcn_readfirstlane(leaf_first);
-                        const uint32_t ucs = __builtin_amdgcn_readfirstlane(leaf_count);
-                        cu4_ptr items = (cu4_ptr)(S.leaf_items);
-                        for (uint32_t k = 0; k < ucs; ++k) {
-                            const u32x4 hq = items[(ufs + k) * 2];
-                            const u32x4 bq = items[(ufs + k) * 2 + 1];
-                            const uint4 head = make_uint4(hq.x, hq.y, hq.z, hq.w);
-                            const float4 body = make_float4(__uint_as_float(bq.x), __uint_as_float(bq.y),
-                                                            __uint_as_float(bq.z), __uint_as_float(bq.w));
-                            test_leaf_item(S, head, body, src, ray, near, ignore, have, best, ctr);
-                        }
-                        mine_done = true;
-                    }
-                }
-            } else {
-                for (uint32_t k = 0; k < leaf_count; ++k) {
-                    const uint4 head = S.leaf_items[(leaf_first + k) * 2];
-                    const uint4 bq = S.leaf_items[(leaf_first + k) * 2 + 1];
-                    const float4 body = make_float4(__uint_as_float(bq.x), __uint_as_float(bq.y),
-                                                    __uint_as_float(bq.z), __uint_as_float(bq.w));
-                    test_leaf_item(S, head, body, src, ray, near, ignore, have, best, ctr);
-                }
-            }
-            r_hit = have;
-            r = best;
-            // unwind
-            bool resumed = false;
-            while (sp > 0) {
-                --sp;
-                const uint2 ent = my_stack[sp * stride];
-                const uint32_t axis = ent.x >> 30;
-                const float plane = __uint_as_float(ent.y);
-                bool take_second = !r_hit;
-                if (r_hit) {
-                    const float endpoint = comp(src, axis) + comp(ray, axis) * r.dist;
-                    const bool under_first = comp(src, axis) < plane;
-                    take_second = under_first ? (endpoint > plane) : (endpoint < plane);
-                }
-                if (take_second) {
-                    cur = ent.x & 0x3fffffffu;
-                    r_hit = false;
-                    resumed = true;
-                    break;
-                }
-            }
-            if (!resumed) done = true;
-        }
-    }
-    out = r;
-    return r_hit;
-}
 
 }  // namespace RT_NS

@@ -1,0 +1,297 @@
+// Closest hit through the flattened space partition (gfx950, wave64), restating
+// SpacePartition::intersect / InteriorNode::intersect / intersect_primitives
+// (reference src/space_partition.rs:268-385).
+//
+// The reference recursion is:  visit(node) = none if the node's box is missed; the leaf's
+// nearest hit for a leaf; else r = visit(child on src's side of the plane) and, if r is
+// none or r's end point lies strictly beyond the plane, visit(other child) INSTEAD of r
+// (:313-325, :331-343).  Iterative form: each interior node on the current path whose far
+// child is still unvisited has one stack entry {far child | axis << 30, plane}.  When a
+// subtree finishes with result r, entries are popped: the first one for which r is none or
+// beyond its plane discards r and descends into its far child; if none does, r is the
+// answer.  The per-lane stack lives in LDS (entry k of thread t at stack[k * blockDim.x + t]);
+// the host guarantees DevScene::stack_depth >= tree depth.
+//
+// Leaves.  The reference walks a leaf's primitives in list order and keeps a hit when it is
+// strictly nearer than the best so far, so of equal distances the first in the list wins
+// (:370-381).  On the device each leaf's list is stored as three runs -- spheres, cones,
+// polygons -- each in list order, every entry carrying its list position; a candidate
+// replaces the best when it is nearer, or equally near with a smaller list position, which
+// selects the same primitive as the sequential walk.
+//
+// Sphere runs are the hot loop of sphere-heavy scenes (the reference's tree degenerates to
+// a few huge leaves when one large polygon spans the scene).  A run is an array of
+// {centre, r*r}, padded to a multiple of 4 entries.  Per entry the loop does only what is
+// needed to decide "discriminant >= 0" -- with d = ray . (src - c) and c = |src - c|^2 - r*r
+// the reference's b*b - 4*a*c (src/sphere.rs:51-56) equals 4 * (fl(d*d) - fl(a*c)) exactly,
+// powers of two commuting with rounding, so its sign test is fl(d*d) >= fl(a*c) -- and only
+// lanes that pass go on to the square root, the divisions, the near test and the ignore
+// test, in the reference's own operation order.  Leaves with >= BIG_LEAF entries are walked
+// by all lanes standing on the same leaf together with a wave-uniform index, so that the
+// entries arrive through scalar loads and stay in SGPRs.
+#pragma once
+#include "rt_shapes.h"
+
+namespace RT_NS {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) f32x4* cf4_ptr;
+typedef const __attribute__((address_space(4))) u32x2* cu2_ptr;
+
+// Loads with a wave-uniform index go through the constant address space (scalar loads).
+template <bool U>
+RT_DEV float4 ld_f4(const float4* p, uint32_t i) {
+    if constexpr (U) {
+        const f32x4 v = ((cf4_ptr)p)[i];
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return p[i];
+    }
+}
+template <bool U>
+RT_DEV uint4 ld_u4(const uint4* p, uint32_t i) {
+    if constexpr (U) {
+        const u32x4 v = ((cu4_ptr)p)[i];
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return p[i];
+    }
+}
+template <bool U>
+RT_DEV uint2 ld_u2(const uint2* p, uint32_t i) {
+    if constexpr (U) {
+        const u32x2 v = ((cu2_ptr)p)[i];
+        return make_uint2(v.x, v.y);
+    } else {
+        return p[i];
+    }
+}
+
+struct Hit {
+    float dist;
+    uint32_t prim;
+    F3 n;
+};
+
+// Nearest hit of one leaf visit.
+struct LeafBest {
+    bool have;
+    float t;
+    uint32_t pos;     // position in the leaf's primitive list (tie-break)
+    uint32_t prim;
+    uint32_t sphere;  // sphere-run entry whose normal is still to be formed, or NO_PRIM
+    F3 n;
+    RT_DEV void init() {
+        have = false; t = 0.0f; pos = 0u; prim = NO_PRIM; sphere = NO_PRIM; n = f3(0.0f, 0.0f, 0.0f);
+    }
+    RT_DEV bool better(float tt, uint32_t p) const { return !have || tt < t || (tt == t && p < pos); }
+};
+
+// Lanes whose quick test passed: the rest of Sphere::intersect (src/sphere.rs:55-76).
+template <bool U, class Ctr>
+RT_DEV void sphere_finish(const DevScene& S, uint32_t entry, float d, float c, float a, float near, uint32_t ignore,
+                          LeafBest& lb, Ctr& ctr) {
+    const float b = 2.0f * d;
+    const float disc = b * b - 4.0f * a * c;
+    if (disc >= 0.0f) {
+        const float sq = sqrtf(disc);
+        float t = (-b - sq) / (2.0f * a);
+        if (t < near) t = (-b + sq) / (2.0f * a);
+        if (t >= near) {
+            const uint2 id = ld_u2<U>(S.sph_id, entry);
+            if (id.x != ignore) {  // src/space_partition.rs:361-366
+                ctr.sphere_hits(1);
+                if (lb.better(t, id.y)) {
+                    lb.have = true; lb.t = t; lb.pos = id.y; lb.prim = id.x; lb.sphere = entry;
+                }
+            }
+        }
+    }
+}
+
+template <bool U, class Ctr>
+RT_DEV void leaf_spheres(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, float a, float near,
+                         uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    for (uint32_t k = 0; k < count; k += 4) {
+        const float4 s0 = ld_f4<U>(S.sph, first + k);
+        const float4 s1 = ld_f4<U>(S.sph, first + k + 1);
+        const float4 s2 = ld_f4<U>(S.sph, first + k + 2);
+        const float4 s3 = ld_f4<U>(S.sph, first + k + 3);
+        const F3 e0 = sub(src, f3(s0.x, s0.y, s0.z));
+        const F3 e1 = sub(src, f3(s1.x, s1.y, s1.z));
+        const F3 e2 = sub(src, f3(s2.x, s2.y, s2.z));
+        const F3 e3 = sub(src, f3(s3.x, s3.y, s3.z));
+        const float d0 = dot(ray, e0), d1 = dot(ray, e1), d2 = dot(ray, e2), d3 = dot(ray, e3);
+        const float c0 = dot(e0, e0) - s0.w, c1 = dot(e1, e1) - s1.w, c2 = dot(e2, e2) - s2.w, c3 = dot(e3, e3) - s3.w;
+        const bool m0 = d0 * d0 >= a * c0;
+        const bool m1 = d1 * d1 >= a * c1;
+        const bool m2 = d2 * d2 >= a * c2;
+        const bool m3 = d3 * d3 >= a * c3;
+        if constexpr (Ctr::kEnabled) {  // the reference skips the ignored primitive before testing it
+            for (uint32_t j = 0; j < 4 && k + j < count; ++j)
+                if (ld_u2<U>(S.sph_id, first + k + j).x != ignore) ctr.sphere_tests(1);
+        }
+        if (m0 | m1 | m2 | m3) {
+            if (m0) sphere_finish<U>(S, first + k, d0, c0, a, near, ignore, lb, ctr);
+            if (m1 && k + 1 < count) sphere_finish<U>(S, first + k + 1, d1, c1, a, near, ignore, lb, ctr);
+            if (m2 && k + 2 < count) sphere_finish<U>(S, first + k + 2, d2, c2, a, near, ignore, lb, ctr);
+            if (m3 && k + 3 < count) sphere_finish<U>(S, first + k + 3, d3, c3, a, near, ignore, lb, ctr);
+        }
+    }
+}
+
+template <bool U, class Ctr>
+RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, float near, uint32_t ignore,
+                       LeafBest& lb, Ctr& ctr) {
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint4 it = ld_u4<U>(S.cone_items, first + k);  // {prim, list position, cone index, -}
+        if (it.x == ignore) continue;
+        ctr.cone_tests(1);
+        const float4 c0 = ld_f4<U>(S.cones, it.z * 2), c1 = ld_f4<U>(S.cones, it.z * 2 + 1);
+        float t;
+        F3 n;
+        if (isect_cone(f3(c0.x, c0.y, c0.z), c0.w, f3(c1.x, c1.y, c1.z), c1.w, src, ray, near, t, n)) {
+            ctr.cone_hits(1);
+            if (lb.better(t, it.y)) {
+                lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
+            }
+        }
+    }
+}
+
+template <bool U, class Ctr>
+RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, float near,
+                          uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint4 it = ld_u4<U>(S.poly_items, first + k);  // {prim, list position, first vertex, n vertices}
+        if (it.x == ignore) continue;
+        ctr.poly_tests(1);
+        float t;
+        F3 n;
+        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, src, ray, near, t, n, ctr)) {
+            ctr.poly_hits(1);
+            if (lb.better(t, it.y)) {
+                lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
+            }
+        }
+    }
+}
+
+template <bool U, class Ctr>
+RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, float a, float near, uint32_t ignore,
+                      LeafBest& lb, Ctr& ctr) {
+    if (q2.y) leaf_spheres<U>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
+    if (q2.w) leaf_cones<U>(S, q2.z, q2.w, src, ray, near, ignore, lb, ctr);
+    if (q3.y) leaf_polygons<U>(S, q3.x, q3.y, src, ray, near, ignore, lb, ctr);
+}
+
+// Result of a finished subtree against the pending stack entries: returns true and sets
+// `cur` when some entry sends the walk into its far child, false when the walk is over.
+RT_DEV bool unwind(const uint2* my_stack, uint32_t stride, uint32_t& sp, F3 src, F3 ray, bool& r_hit, float r_dist,
+                   uint32_t& cur) {
+    while (sp > 0) {
+        --sp;
+        const uint2 ent = my_stack[sp * stride];
+        const uint32_t axis = ent.x >> 30;
+        const float plane = __uint_as_float(ent.y);
+        bool take_second = !r_hit;
+        if (r_hit) {
+            const float endpoint = comp(src, axis) + comp(ray, axis) * r_dist;  // src/space_partition.rs:316, :334
+            const bool under_first = comp(src, axis) < plane;
+            take_second = under_first ? (endpoint > plane) : (endpoint < plane);
+        }
+        if (take_second) {
+            cur = ent.x & 0x3fffffffu;
+            r_hit = false;
+            return true;
+        }
+    }
+    return false;
+}
+
+template <class Ctr>
+RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
+                                uint2* stack, Ctr& ctr) {
+    RayInv ri;
+#if RT_FAST
+    ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+#endif
+    const float a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
+    const uint32_t stride = blockDim.x;
+    uint2* my_stack = stack + threadIdx.x;
+    uint32_t sp = 0;
+    uint32_t cur = 0;
+    bool done = false;
+    bool r_hit = false;
+    Hit r;
+    r.dist = 0.0f; r.prim = NO_PRIM; r.n = f3(0.0f, 0.0f, 0.0f);
+
+    while (!done) {
+        // ---- walk until this lane stands on a leaf whose box it hits, or is finished
+        bool at_leaf = false;
+        uint4 q2 = make_uint4(0, 0, 0, 0), q3 = make_uint4(0, 0, 0, 0);
+        while (!done && !at_leaf) {
+            const uint4 q0 = S.nodes[cur * 4 + 0];
+            const uint4 q1 = S.nodes[cur * 4 + 1];
+            ctr.node_visits(1);
+            const F3 bmin = f3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            const F3 bmax = f3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+            if (aabb_slab_test(bmin, bmax, src, ray, near, ri)) {  // :276-279
+                q2 = S.nodes[cur * 4 + 2];
+                const uint32_t axis = q1.w;
+                if (axis == AXIS_LEAF) {
+                    q3 = S.nodes[cur * 4 + 3];
+                    at_leaf = true;
+                } else {
+                    ctr.interior_steps(1);
+                    const float plane = __uint_as_float(q0.w);
+                    const bool under_first = comp(src, axis) < plane;  // :303
+                    my_stack[sp * stride] = make_uint2((under_first ? q2.y : q2.x) | (axis << 30), q0.w);
+                    ++sp;
+                    cur = under_first ? q2.x : q2.y;
+                }
+            } else {
+                r_hit = false;
+                if (!unwind(my_stack, stride, sp, src, ray, r_hit, r.dist, cur)) done = true;
+            }
+        }
+
+        if (at_leaf) {
+            LeafBest lb;
+            lb.init();
+            if (q2.y + q2.w + q3.y >= BIG_LEAF) {
+                // all lanes standing on the same leaf walk it together, index wave-uniform
+                bool mine_done = false;
+                while (!mine_done) {
+                    if (cur == (uint32_t)__builtin_amdgcn_readfirstlane(cur)) {
+                        // (read again inside the branch: these copies stay in scalar registers)
+                        const uint4 u2 = make_uint4(__builtin_amdgcn_readfirstlane(q2.x), __builtin_amdgcn_readfirstlane(q2.y),
+                                                    __builtin_amdgcn_readfirstlane(q2.z), __builtin_amdgcn_readfirstlane(q2.w));
+                        const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y), 0u, 0u);
+                        leaf_runs<true>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
+                        mine_done = true;
+                    }
+                }
+            } else {
+                leaf_runs<false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
+            }
+            r_hit = lb.have;
+            if (lb.have) {
+                r.dist = lb.t;
+                r.prim = lb.prim;
+                if (lb.sphere != NO_PRIM) {
+                    const float4 s = S.sph[lb.sphere];
+                    r.n = sphere_normal(f3(s.x, s.y, s.z), src, ray, lb.t);
+                } else {
+                    r.n = lb.n;
+                }
+            }
+            if (!unwind(my_stack, stride, sp, src, ray, r_hit, r.dist, cur)) done = true;
+        }
+    }
+    out = r;
+    return r_hit;
+}
+
+}  // namespace RT_NS
