@@ -51,9 +51,12 @@ struct rt_context {
     int device = 0;
     std::string err;
     // frame workspace, kept across calls and grown on demand
-    DevBuf<float4> ray_o, ray_d, node_col;
+    DevBuf<float4> ray_o, ray_d, node_col, hit_a, sray_o, sray_d;
+    DevBuf<uint32_t> hit_p, sray_blocked;
+    DevBuf<uint2> node_sh;
+    size_t shadow_cap = 0;
     DevBuf<uint4> node_kid;
-    DevBuf<uint32_t> levels;  // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | overflow
+    DevBuf<uint32_t> levels;  // level_count | level_base | shadow_count (RT_MAX_LEVELS each) | overflow
     DevBuf<unsigned long long> counters;
     size_t pool_cap = 0;
     DevBuf<float> out_f32;
@@ -101,7 +104,19 @@ int ensure_pool(rt_context* ctx, size_t cap) {
     RT_HIP(ctx, ctx->ray_d.alloc(cap));
     RT_HIP(ctx, ctx->node_col.alloc(cap));
     RT_HIP(ctx, ctx->node_kid.alloc(cap));
+    RT_HIP(ctx, ctx->hit_a.alloc(cap));
+    RT_HIP(ctx, ctx->hit_p.alloc(cap));
+    RT_HIP(ctx, ctx->node_sh.alloc(cap));
     ctx->pool_cap = cap;
+    return RT_OK;
+}
+
+int ensure_shadow(rt_context* ctx, size_t cap) {
+    if (ctx->shadow_cap >= cap) return RT_OK;
+    RT_HIP(ctx, ctx->sray_o.alloc(cap));
+    RT_HIP(ctx, ctx->sray_d.alloc(cap));
+    RT_HIP(ctx, ctx->sray_blocked.alloc(cap));
+    ctx->shadow_cap = cap;
     return RT_OK;
 }
 
@@ -126,7 +141,7 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, RT_ERR_UNSUPPORTED, std::string("librtamd is built for gfx950 only; device is ") + prop.gcnArchName);
     for (auto& e : ctx->ev) RT_HIP(ctx, hipEventCreate(&e));
-    RT_HIP(ctx, ctx->levels.alloc(2 * RT_MAX_LEVELS + 1));
+    RT_HIP(ctx, ctx->levels.alloc(3 * RT_MAX_LEVELS + 1));
     RT_HIP(ctx, ctx->counters.alloc(17));
     return RT_OK;
 }
@@ -353,50 +368,71 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
 
     const bool fast = opt->fp_mode == RT_FP_FAST;
     const bool work = opt->collect_work != 0;
+    const uint32_t n_lights = scene->dev.n_lights;
     size_t cap = std::max<size_t>(ctx->pool_cap, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
+    size_t scap = std::max<size_t>(ctx->shadow_cap, std::max<size_t>((size_t)n_slots * n_lights, 1u << 16));
     rt_stats stats;
     memset(&stats, 0, sizeof(stats));
+    uint32_t lv[3 * RT_MAX_LEVELS + 1];
 
     for (uint32_t attempt = 0;; ++attempt) {
-        if (cap > 0xfffffff0ull) return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
+        if (cap > 0xfffffff0ull || scap > 0xfffffff0ull)
+            return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
         rc = ensure_pool(ctx, cap);
+        if (rc != RT_OK) return rc;
+        rc = ensure_shadow(ctx, scap);
         if (rc != RT_OK) return rc;
         A.ray_o = ctx->ray_o.p;
         A.ray_d = ctx->ray_d.p;
+        A.hit_a = ctx->hit_a.p;
+        A.hit_p = ctx->hit_p.p;
+        A.node_sh = ctx->node_sh.p;
         A.node_col = ctx->node_col.p;
         A.node_kid = ctx->node_kid.p;
         A.pool_cap = (uint32_t)ctx->pool_cap;
+        A.sray_o = ctx->sray_o.p;
+        A.sray_d = ctx->sray_d.p;
+        A.sray_blocked = ctx->sray_blocked.p;
+        A.shadow_cap = (uint32_t)ctx->shadow_cap;
         A.level_count = ctx->levels.p;
         A.level_base = ctx->levels.p + RT_MAX_LEVELS;
-        A.overflow = ctx->levels.p + 2 * RT_MAX_LEVELS;
+        A.shadow_count = ctx->levels.p + 2 * RT_MAX_LEVELS;
+        A.overflow = ctx->levels.p + 3 * RT_MAX_LEVELS;
         A.counters = ctx->counters.p;
 
-        RT_HIP(ctx, hipMemsetAsync(ctx->levels.p, 0, (2 * RT_MAX_LEVELS + 1) * sizeof(uint32_t), st));
+        RT_HIP(ctx, hipMemsetAsync(ctx->levels.p, 0, (3 * RT_MAX_LEVELS + 1) * sizeof(uint32_t), st));
         RT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 17 * sizeof(unsigned long long), st));
         RT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
 
-        const uint32_t grid0 = (n_slots + RT_BLOCK - 1) / RT_BLOCK;
+        const uint32_t grid0 = std::max<uint32_t>(1, (n_slots + RT_BLOCK - 1) / RT_BLOCK);
         // Deeper levels' sizes are only known on the device; launch enough blocks for the
         // largest plausible level and let blocks past the end exit (grid-stride inside).
-        const uint32_t gridn = std::max<uint32_t>(1, std::min<uint32_t>(grid0, 16384));
+        const uint32_t gridn = std::min<uint32_t>(grid0, 16384);
+        const uint32_t grids = (uint32_t)std::min<uint64_t>(
+            std::max<uint64_t>(1, ((uint64_t)n_slots * n_lights + RT_BLOCK - 1) / RT_BLOCK), 65536);
         for (uint32_t level = 0; level <= opt->max_depth; ++level) {
-            const uint32_t g = level == 0 ? std::max<uint32_t>(1, grid0) : gridn;
-            RT_HIP(ctx, fast ? rt_fast::launch_trace(A, level, work, g, st) : rt_exact::launch_trace(A, level, work, g, st));
+            const uint32_t g = level == 0 ? grid0 : gridn;
+            RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, g, st) : rt_exact::launch_intersect(A, level, work, g, st));
+            if (n_lights)
+                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, grids, st) : rt_exact::launch_shadow(A, level, work, grids, st));
+            RT_HIP(ctx, fast ? rt_fast::launch_shade(A, level, work, g, st) : rt_exact::launch_shade(A, level, work, g, st));
         }
         RT_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         for (uint32_t level = opt->max_depth + 1; level-- > 0;) {
-            const uint32_t g = level == 0 ? std::max<uint32_t>(1, grid0) : gridn;
+            const uint32_t g = level == 0 ? grid0 : gridn;
             RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));
         }
         RT_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         RT_HIP(ctx, hipStreamSynchronize(st));
 
-        uint32_t lv[2 * RT_MAX_LEVELS + 1];
         RT_HIP(ctx, hipMemcpy(lv, ctx->levels.p, sizeof(lv), hipMemcpyDeviceToHost));
-        if (lv[2 * RT_MAX_LEVELS] != 0) {  // pool overflow: grow and run the frame again
-            uint64_t need = n_slots;
+        if (lv[3 * RT_MAX_LEVELS] != 0) {  // a pool overflowed: grow and run the frame again
+            uint64_t need = n_slots, sneed = 0;
             for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
-            cap = std::max<size_t>(ctx->pool_cap * 2, (size_t)need + (need >> 2));
+            for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed = std::max<uint64_t>(sneed, lv[2 * RT_MAX_LEVELS + l]);
+            if (need > ctx->pool_cap) cap = std::max<size_t>(ctx->pool_cap * 2, (size_t)need + (need >> 2));
+            if (sneed > ctx->shadow_cap) scap = std::max<size_t>(ctx->shadow_cap * 2, (size_t)sneed + (sneed >> 2));
+            if (need <= ctx->pool_cap && sneed <= ctx->shadow_cap) { cap = ctx->pool_cap * 2; scap = ctx->shadow_cap * 2; }
             stats.retries = attempt + 1;
             if (attempt >= 8) return fail(ctx, RT_ERR_CAPACITY, "ray pool still too small after 8 growth steps");
             continue;
@@ -404,7 +440,8 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         unsigned long long c[17];
         RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         stats.rays_primary = n_primary;
-        stats.rays_shadow = c[1];
+        stats.rays_shadow = 0;
+        for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += lv[2 * RT_MAX_LEVELS + l];
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
         for (int k = 0; k < 13; ++k) stats.work[k] = c[4 + k];

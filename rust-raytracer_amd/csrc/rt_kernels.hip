@@ -2,16 +2,20 @@
 // -ffp-contract=off, and -DRT_FAST=1 -DRT_NS=rt_fast with contraction on.
 //
 // Frame structure (replaces the recursion of Scene::sub_trace, reference src/scene.rs:82-200):
-// the ray tree is evaluated level by level.  Level 0 holds one ray per pixel slot; the
-// trace kernel of level d intersects each of its rays, does the direct lighting with its
-// shadow rays (src/scene.rs:103-125), and appends the reflection / refraction rays it
-// spawns (src/scene.rs:127-193) to level d+1 using a wave-wide ballot + prefix count and
-// one atomic per wave.  Every ray owns one node in a pool (node index = ray index): the
-// node keeps the direct colour, the two child indices and their weights.  After the last
-// level, resolve kernels run from the deepest level up: total = direct + refl * reflectance
-// + refr * transmittance in that order, clamped per node exactly as src/scene.rs:195 does
-// before the parent multiplies it -- the clamp makes the recursion non-linear, so path
-// throughput accumulation would not reproduce it.
+// the ray tree is evaluated level by level.  Level 0 holds one ray per pixel slot.  Every
+// ray owns one node in a pool (node index = ray index).  Per level three kernels run:
+//   k_intersect  closest hit of every ray of the level (src/scene.rs:90); for each front-face
+//                hit it appends one shadow ray per light (src/scene.rs:103-112) to the shadow
+//                queue with a wave-wide ballot + prefix count and one atomic per wave;
+//   k_shadow     closest hit of every shadow ray -> blocked flag (src/scene.rs:108-117);
+//   k_shade      direct lighting from the unblocked lights in light order (src/scene.rs:119-124),
+//                then appends the reflection / refraction rays the hit spawns
+//                (src/scene.rs:127-193) to level d+1, again by ballot + prefix count.
+// The node keeps the direct colour, the two child indices and their weights.  After the
+// last level, resolve kernels run from the deepest level up: total = direct + refl *
+// reflectance + refr * transmittance in that order, clamped per node exactly as
+// src/scene.rs:195 does before the parent multiplies it -- the clamp makes the recursion
+// non-linear, so path-throughput accumulation would not reproduce it.
 #include <hip/hip_runtime.h>
 
 #include "rt_traverse.h"
@@ -33,6 +37,16 @@ RT_DEV uint32_t prefix_count(uint64_t mask) {  // set bits of `mask` below this 
 RT_DEV uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+template <class Ctr>
+RT_DEV void flush_work(const FrameArgs& A, Ctr& ctr) {
+    if constexpr (Ctr::kEnabled) {
+        for (int k = 0; k < 13; ++k) {
+            const uint32_t s = wave_sum(ctr.c[k]);
+            if (lane_id() == 0 && s) atomicAdd(&A.counters[4 + k], (unsigned long long)s);
+        }
+    }
 }
 
 RT_DEV Surface load_surface(const DevScene& S, uint32_t id) {
@@ -66,54 +80,151 @@ RT_DEV uint32_t level_size(const FrameArgs& A, uint32_t level, uint32_t base) {
     return wanted < room ? wanted : room;
 }
 
+struct Ray {
+    F3 src, dir;
+    float near, contribution;
+    uint32_t ignore;
+};
+
+// Ray of node `node` (position i in its level).  Level 0: the camera ray of the slot's pixel,
+// src/render.rs:101-108; deeper levels: read from the pool.  Returns false for padding slots.
+template <bool LEVEL0>
+RT_DEV bool fetch_ray(const FrameArgs& A, uint32_t i, uint32_t node, Ray& r) {
+    if (LEVEL0) {
+        uint32_t px = 0, py = 0;
+        if (!slot_to_pixel(A, i, px, py)) return false;
+        const float sy = 1.0f - ((float)(2 * (int)py + 1)) / ((float)A.height);
+        const float sx = -1.0f + ((float)(2 * (int)px + 1)) / ((float)A.width);
+        const F3 fwd = f3(A.fwd[0], A.fwd[1], A.fwd[2]);
+        const F3 up = f3(A.up[0], A.up[1], A.up[2]);
+        const F3 right = f3(A.right[0], A.right[1], A.right[2]);
+        r.dir = normalized(add(add(fwd, mul(up, sy)), mul(right, sx)));
+        r.src = f3(A.from[0], A.from[1], A.from[2]);
+        r.near = A.hither;
+        r.contribution = 1.0f;
+        r.ignore = NO_PRIM;
+    } else {
+        const float4 ro = A.ray_o[node];
+        const float4 rd = A.ray_d[node];
+        r.src = f3(ro.x, ro.y, ro.z);
+        r.contribution = ro.w;
+        r.dir = f3(rd.x, rd.y, rd.z);
+        r.ignore = __float_as_uint(rd.w);
+        // reflection rays ignore their surface and start at 0; refraction rays ignore
+        // nothing and start at 0.0001 (src/scene.rs:136-137, :186-187)
+        r.near = r.ignore == NO_PRIM ? 0.0001f : 0.0f;
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
-// trace: one bounce level
+// k_intersect: closest hit of every ray of one level + its shadow rays
 // ---------------------------------------------------------------------------------------
 template <bool LEVEL0, class Ctr>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace(FrameArgs A, uint32_t level) {
+__global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
     const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
     const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
-    const uint32_t next_base = base + count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = next_base;
-
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = base + count;
+    const uint32_t n_lights = S.n_lights;
     Ctr ctr;
-    uint32_t n_shadow = 0, n_refl = 0, n_refr = 0;
 
     for (uint32_t chunk = blockIdx.x * RT_BLOCK; chunk < count; chunk += gridDim.x * RT_BLOCK) {
         const uint32_t i = chunk + threadIdx.x;
-        bool active = i < count;
         const uint32_t node = base + i;
+        Ray ray;
+        ray.src = f3(0, 0, 0); ray.dir = f3(1, 0, 0); ray.near = 0.0f; ray.contribution = 0.0f; ray.ignore = NO_PRIM;
+        const bool active = i < count && fetch_ray<LEVEL0>(A, i, node, ray);
 
-        F3 src, ray;
-        float near, contribution;
-        uint32_t ignore;
-        if (LEVEL0) {
-            uint32_t px = 0, py = 0;
-            active = active && slot_to_pixel(A, i, px, py);
-            // src/render.rs:101-108
-            const float sy = 1.0f - ((float)(2 * (int)py + 1)) / ((float)A.height);
-            const float sx = -1.0f + ((float)(2 * (int)px + 1)) / ((float)A.width);
-            const F3 fwd = f3(A.fwd[0], A.fwd[1], A.fwd[2]);
-            const F3 up = f3(A.up[0], A.up[1], A.up[2]);
-            const F3 right = f3(A.right[0], A.right[1], A.right[2]);
-            ray = normalized(add(add(fwd, mul(up, sy)), mul(right, sx)));
-            src = f3(A.from[0], A.from[1], A.from[2]);
-            near = A.hither;
-            contribution = 1.0f;
-            ignore = NO_PRIM;
-        } else {
-            const float4 ro = active ? A.ray_o[node] : make_float4(0, 0, 0, 0);
-            const float4 rd = active ? A.ray_d[node] : make_float4(1, 0, 0, 0);
-            src = f3(ro.x, ro.y, ro.z);
-            contribution = ro.w;
-            ray = f3(rd.x, rd.y, rd.z);
-            ignore = __float_as_uint(rd.w);
-            // reflection rays ignore their surface and start at 0; refraction rays ignore
-            // nothing and start at 0.0001 (src/scene.rs:136-137, :186-187)
-            near = ignore == NO_PRIM ? 0.0001f : 0.0f;
+        bool lit = false;  // front-face hit: needs its shadow rays
+        Hit hit;
+        hit.dist = 0.0f; hit.prim = NO_PRIM; hit.n = f3(0, 0, 0);
+        if (active) {
+            const bool ok = kd_traverse_closest(S, ray.src, ray.dir, ray.near, ray.ignore, hit, lds_stack, ctr);
+            if (!ok) hit.prim = NO_PRIM;
+            A.hit_a[node] = make_float4(hit.n.x, hit.n.y, hit.n.z, hit.dist);
+            A.hit_p[node] = hit.prim;
+            if (ok) {
+                ctr.surface_hits(1);
+                lit = !(dot(hit.n, ray.dir) > 0.0f) && n_lights > 0;  // src/scene.rs:96, :102
+            }
         }
+        // ---- one shadow ray per light for every front-face hit; a wave's rays of one light are adjacent
+        const uint64_t m_lit = __ballot(lit);
+        const uint32_t c_lit = (uint32_t)__popcll(m_lit);
+        if (c_lit) {
+            uint32_t slot0 = 0;
+            if (lane_id() == 0) slot0 = atomicAdd(&A.shadow_count[level], c_lit * n_lights);
+            slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            if (lit) {
+                const uint32_t first = slot0 + prefix_count(m_lit);
+                const bool fits = slot0 + c_lit * n_lights <= A.shadow_cap;
+                if (!fits) *A.overflow = 1u;
+                A.node_sh[node] = make_uint2(fits ? first : NONE, c_lit);
+                if (fits) {
+                    const F3 pos = add(ray.src, mul(ray.dir, hit.dist));  // src/scene.rs:95
+                    for (uint32_t l = 0; l < n_lights; ++l) {             // src/scene.rs:103-112
+                        ctr.light_evals(1);
+                        const float4 lp = S.lights[l * 2];
+                        const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
+                        const float ldist = magnitude(to_light);
+                        const F3 ldir = divs(to_light, ldist);
+                        const uint32_t s = first + l * c_lit;
+                        A.sray_o[s] = make_float4(pos.x, pos.y, pos.z, ldist);
+                        A.sray_d[s] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(hit.prim));
+                    }
+                }
+            }
+        }
+        if (active && !lit) A.node_sh[node] = make_uint2(NONE, 0u);
+    }
+    flush_work(A, ctr);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_shadow: is anything between the surface point and the light (src/scene.rs:108-117):
+// a full closest-hit query ignoring the surface's own primitive, blocked iff its distance
+// <= the light's distance.
+// ---------------------------------------------------------------------------------------
+template <class Ctr>
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(FrameArgs A, uint32_t level) {
+    extern __shared__ uint2 lds_stack[];
+    const DevScene& S = A.scene;
+    const uint32_t wanted = A.shadow_count[level];
+    const uint32_t count = wanted < A.shadow_cap ? wanted : A.shadow_cap;
+    Ctr ctr;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
+        const float4 so = A.sray_o[i];
+        const float4 sd = A.sray_d[i];
+        Hit blocker;
+        bool blocked = false;
+        if (kd_traverse_closest(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
+                                lds_stack, ctr))
+            blocked = blocker.dist <= so.w;
+        A.sray_blocked[i] = blocked ? 1u : 0u;
+    }
+    flush_work(A, ctr);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_shade: direct lighting + spawning the next level
+// ---------------------------------------------------------------------------------------
+template <bool LEVEL0, class Ctr>
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(FrameArgs A, uint32_t level) {
+    const DevScene& S = A.scene;
+    const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
+    const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
+    const uint32_t next_base = base + count;
+    Ctr ctr;
+    uint32_t n_refl = 0, n_refr = 0;
+
+    for (uint32_t chunk = blockIdx.x * RT_BLOCK; chunk < count; chunk += gridDim.x * RT_BLOCK) {
+        const uint32_t i = chunk + threadIdx.x;
+        const uint32_t node = base + i;
+        Ray ray;
+        ray.src = f3(0, 0, 0); ray.dir = f3(1, 0, 0); ray.near = 0.0f; ray.contribution = 0.0f; ray.ignore = NO_PRIM;
+        const bool active = i < count && fetch_ray<LEVEL0>(A, i, node, ray);
 
         F3 total = f3(0.0f, 0.0f, 0.0f);
         bool want_refl = false, want_refr = false, is_hit = false;
@@ -122,41 +233,33 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(FrameArgs A, uint32_t level)
         uint32_t hit_prim = NO_PRIM;
 
         if (active) {
-            Hit hit;
-            if (kd_traverse_closest(S, src, ray, near, ignore, hit, lds_stack, ctr)) {
+            hit_prim = A.hit_p[node];
+            if (hit_prim != NO_PRIM) {
                 is_hit = true;
-                ctr.surface_hits(1);
-                hit_prim = hit.prim;
-                const Surface surf = load_surface(S, S.prim_surface[hit.prim]);
-                const F3 normal = hit.n;
-                pos = add(src, mul(ray, hit.dist));            // src/scene.rs:95
-                const bool back_face = dot(normal, ray) > 0.0f;  // :96
-
+                const float4 ha = A.hit_a[node];
+                const F3 normal = f3(ha.x, ha.y, ha.z);
+                const Surface surf = load_surface(S, S.prim_surface[hit_prim]);
+                pos = add(ray.src, mul(ray.dir, ha.w));               // src/scene.rs:95
+                const bool back_face = dot(normal, ray.dir) > 0.0f;   // :96
                 if (!back_face) {
-                    for (uint32_t l = 0; l < S.n_lights; ++l) {  // :103-125
-                        ctr.light_evals(1);
-                        const float4 lp = S.lights[l * 2], lc = S.lights[l * 2 + 1];
-                        const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
-                        const float ldist = magnitude(to_light);
-                        const F3 ldir = divs(to_light, ldist);
-                        ++n_shadow;
-                        Hit blocker;
-                        bool blocked = false;
-                        if (kd_traverse_closest(S, pos, ldir, 0.0f, hit.prim, blocker, lds_stack, ctr))
-                            blocked = blocker.dist <= ldist;
-                        if (!blocked) {
+                    const uint2 sh = A.node_sh[node];
+                    for (uint32_t l = 0; l < S.n_lights && sh.x != NONE; ++l) {  // :103-125, in light order
+                        const uint32_t s = sh.x + l * sh.y;
+                        if (A.sray_blocked[s] == 0u) {
                             ctr.shade_evals(1);
-                            const F3 lcol = f3(lc.x, lc.y, lc.z);
-                            const F3 direct = surf.model == 0u ? shade_phong(surf, normal, ray, ldir, lcol)
-                                                               : shade_blinn_phong(surf, normal, ray, ldir, lcol);
+                            const float4 sd = A.sray_d[s];
+                            const float4 lc = S.lights[l * 2 + 1];
+                            const F3 ldir = f3(sd.x, sd.y, sd.z), lcol = f3(lc.x, lc.y, lc.z);
+                            const F3 direct = surf.model == 0u ? shade_phong(surf, normal, ray.dir, ldir, lcol)
+                                                               : shade_blinn_phong(surf, normal, ray.dir, ldir, lcol);
                             total = add(total, direct);
                         }
                     }
                     if (level < A.max_depth) {  // :127-144
-                        refl_contrib = contribution * surf.reflectance;
+                        refl_contrib = ray.contribution * surf.reflectance;
                         if (refl_contrib > A.min_contribution) {
                             want_refl = true;
-                            refl_ray = reflect(ray, normal);
+                            refl_ray = reflect(ray.dir, normal);
                             reflectance = surf.reflectance;
                         }
                     }
@@ -164,10 +267,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(FrameArgs A, uint32_t level)
                 if (level < A.max_depth) {  // :147-193
                     if (back_face) transmittance = surf.transmittance > A.min_contribution ? 1.0f : 0.0f;
                     else transmittance = surf.transmittance;
-                    refr_contrib = contribution * transmittance;
+                    refr_contrib = ray.contribution * transmittance;
                     if (refr_contrib > A.min_contribution) {
                         want_refr = true;
-                        refr_ray = back_face ? refract(ray, neg(normal), 1.0f / surf.ior) : refract(ray, normal, surf.ior);
+                        refr_ray = back_face ? refract(ray.dir, neg(normal), 1.0f / surf.ior)
+                                             : refract(ray.dir, normal, surf.ior);
                     }
                 }
             } else {
@@ -212,19 +316,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(FrameArgs A, uint32_t level)
         }
     }
 
-    // ---- counters: one atomic per wave and counter
-    const uint32_t s_shadow = wave_sum(n_shadow), s_refl = wave_sum(n_refl), s_refr = wave_sum(n_refr);
+    const uint32_t s_refl = wave_sum(n_refl), s_refr = wave_sum(n_refr);
     if (lane_id() == 0) {
-        if (s_shadow) atomicAdd(&A.counters[1], (unsigned long long)s_shadow);
         if (s_refl) atomicAdd(&A.counters[2], (unsigned long long)s_refl);
         if (s_refr) atomicAdd(&A.counters[3], (unsigned long long)s_refr);
     }
-    if constexpr (sizeof(Ctr) > 4) {
-        for (int k = 0; k < 13; ++k) {
-            const uint32_t s = wave_sum(ctr.c[k]);
-            if (lane_id() == 0 && s) atomicAdd(&A.counters[4 + k], (unsigned long long)s);
-        }
-    }
+    flush_work(A, ctr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -392,8 +489,9 @@ static size_t stack_bytes(const DevScene& S) { return (size_t)S.stack_depth * RT
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
 hipError_t init_kernels() {
     const int max_lds = 160 * 1024;
-    const void* fns[] = {(const void*)k_trace<true, WorkCounters>, (const void*)k_trace<true, NoCounters>,
-                         (const void*)k_trace<false, WorkCounters>, (const void*)k_trace<false, NoCounters>,
+    const void* fns[] = {(const void*)k_intersect<true, WorkCounters>, (const void*)k_intersect<true, NoCounters>,
+                         (const void*)k_intersect<false, WorkCounters>, (const void*)k_intersect<false, NoCounters>,
+                         (const void*)k_shadow<WorkCounters>, (const void*)k_shadow<NoCounters>,
                          (const void*)k_debug_intersect};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -402,14 +500,32 @@ hipError_t init_kernels() {
     return hipSuccess;
 }
 
-hipError_t launch_trace(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
+hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
     if (level == 0) {
-        if (work) hipLaunchKernelGGL((k_trace<true, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
-        else hipLaunchKernelGGL((k_trace<true, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        if (work) hipLaunchKernelGGL((k_intersect<true, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        else hipLaunchKernelGGL((k_intersect<true, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
     } else {
-        if (work) hipLaunchKernelGGL((k_trace<false, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
-        else hipLaunchKernelGGL((k_trace<false, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        if (work) hipLaunchKernelGGL((k_intersect<false, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        else hipLaunchKernelGGL((k_intersect<false, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
+    const size_t lds = stack_bytes(A.scene);
+    if (work) hipLaunchKernelGGL((k_shadow<WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+    else hipLaunchKernelGGL((k_shadow<NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
+    if (level == 0) {
+        if (work) hipLaunchKernelGGL((k_shade<true, WorkCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+        else hipLaunchKernelGGL((k_shade<true, NoCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+    } else {
+        if (work) hipLaunchKernelGGL((k_shade<false, WorkCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+        else hipLaunchKernelGGL((k_shade<false, NoCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
     }
     return hipGetLastError();
 }

@@ -45,11 +45,20 @@ struct FrameArgs {
     // ray / node pool: index = level_base[level] + position in level
     float4* ray_o;     // origin.xyz, contribution
     float4* ray_d;     // direction.xyz, bits(ignore primitive)
+    float4* hit_a;     // closest hit: normal.xyz, distance
+    uint32_t* hit_p;   // closest hit: primitive, 0xffffffff = miss
+    uint2* node_sh;    // shadow rays of this node's hit: {slot of light 0, slot stride between lights}
     float4* node_col;  // direct (later total) colour, reflectance weight
     uint4* node_kid;   // reflection child, refraction child, bits(transmittance weight), hit flag
     uint32_t pool_cap;
     uint32_t* level_count;  // [RT_MAX_LEVELS]
     uint32_t* level_base;   // [RT_MAX_LEVELS]
+    // shadow-ray queue of the level in flight (reused by every level)
+    float4* sray_o;         // origin.xyz, distance to the light
+    float4* sray_d;         // direction.xyz, bits(ignored primitive)
+    uint32_t* sray_blocked; // 1 = a primitive lies between the surface and the light
+    uint32_t shadow_cap;
+    uint32_t* shadow_count; // [RT_MAX_LEVELS]
     uint32_t* overflow;
     unsigned long long* counters;  // [17]: primary, shadow, reflect, refract, then the 13 work counters
     // outputs (either may be null)
@@ -69,7 +78,9 @@ struct DeinterleaveArgs {
 #define RT_DECLARE_LAUNCHERS(NS)                                                                                     \
     namespace NS {                                                                                                   \
     hipError_t init_kernels();                                                                                       \
-    hipError_t launch_trace(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st);    \
+    hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st); \
+    hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st);   \
+    hipError_t launch_shade(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st);    \
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
     hipError_t launch_debug_intersect(const rtamd::DevScene& S, uint64_t n, const float* src, const float* ray,      \
