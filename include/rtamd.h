@@ -124,10 +124,13 @@ typedef struct rt_options {
     uint32_t fp_mode;        /* RT_FP_* */
     uint32_t tile_rank;      /* this context renders 8x8 tiles t with t % tile_count == tile_rank */
     uint32_t tile_count;     /* 0 or 1 = whole image */
-    uint32_t collect_work;   /* nonzero: also count node visits / shape tests (slower kernels) */
+    uint32_t collect_work;   /* nonzero: also count node visits / shape tests (slower kernels;
+                                implies exhaustive_leaves, so the counts are the reference's work) */
+    uint32_t exhaustive_leaves; /* nonzero: test every primitive of every visited leaf as the reference
+                                does; 0 (default): big leaves skip groups of spheres whose bounding
+                                sphere proves that the reference's test rejects them -- same image */
 } rt_options;
 
-#define RT_N_WORK 17
 typedef struct rt_stats {
     /* one ray = one root call of SpacePartition::intersect (src/space_partition.rs:268) */
     uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
@@ -218,7 +221,9 @@ void rt_camera_basis(const rt_view* view, float* out9);
 /* ---- diagnostics used by the parity tests (device routines run one per lane) ---- */
 
 /* Closest-hit queries through the device traversal (src/space_partition.rs:268);
- * host arrays; ignore[i] = 0xffffffff for none; out_prim[i] = 0xffffffff on a miss. */
+ * host arrays; ignore[i] = 0xffffffff for none; out_prim[i] = 0xffffffff on a miss.
+ * fp_mode may be OR-ed with RT_DEBUG_EXHAUSTIVE (walk leaves without culling). */
+#define RT_DEBUG_EXHAUSTIVE 0x100u
 int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32_t fp_mode, uint64_t n, const float* src,
                        const float* ray, const float* near, const uint32_t* ignore, uint32_t* out_prim,
                        float* out_dist, float* out_normal);

@@ -22,6 +22,7 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_BUILD, RT_ERR_PARSE, RT_ERR_IO, RT_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 FP_EXACT, FP_FAST = 0, 1
+DEBUG_EXHAUSTIVE = 0x100
 KIND_SPHERE, KIND_CONE, KIND_POLYGON = 0, 1, 2
 NO_PRIM = 0xFFFFFFFF
 
@@ -108,7 +109,8 @@ class rt_scene_desc(C.Structure):
 
 class rt_options(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("min_contribution", C.c_float), ("fp_mode", C.c_uint32),
-                ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32), ("collect_work", C.c_uint32)]
+                ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32), ("collect_work", C.c_uint32),
+                ("exhaustive_leaves", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
@@ -332,10 +334,11 @@ class RenderOptions:
     tile_rank: int = 0
     tile_count: int = 1
     collect_work: bool = False
+    exhaustive_leaves: bool = False  # True: no bounding-sphere culling inside big leaves (same image, slower)
 
     def c(self):
         return rt_options(self.max_depth, self.min_contribution, self.fp_mode, self.tile_rank, self.tile_count,
-                          int(self.collect_work))
+                          int(self.collect_work), int(self.exhaustive_leaves))
 
 
 class Scene:

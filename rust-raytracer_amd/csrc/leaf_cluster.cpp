@@ -1,0 +1,119 @@
+// Bounding-sphere hierarchy over the spheres of one leaf (host side).
+//
+// The reference walks every primitive of a leaf (src/space_partition.rs:348-385); when its
+// tree degenerates into leaves of thousands of spheres that walk is the whole cost.  The
+// device may skip a group of spheres when it can PROVE that the reference's test would reject
+// each of them for this ray.  Groups: 8 consecutive entries of the (spatially re-ordered)
+// sphere run form a cluster, 16 consecutive clusters a super-cluster; each gets a bounding
+// record {centre C, q}.  Re-ordering is free: list order only matters for ties, and every
+// entry keeps its list position for that.
+//
+// What the reference can accept.  With u = 2^-24, e = src - c, a = |ray|^2, Sphere::intersect
+// (src/sphere.rs:49-56) returns a hit only if fl(b*b - 4*a*c) >= 0.  Bounding the rounding of
+// its 3 subtractions, two dot products, r*r and the products gives
+//     disc/4 >= (ray.e)^2 - a*(|e|^2 - r^2) - a*(19u |e|^2 + 6u r^2),
+// so acceptance implies  dist(line, c)^2 <= r^2 (1 + 6u) + 19u |e|^2,  i.e.
+//     dist(line, c) <= r (1 + 3u) + k0 |e|,   k0 = sqrt(19u) = 1.07e-3.
+// For a sphere inside a bounding sphere (C, R) (|c - C| + r <= R) and E = src - C this gives
+//     dist(line, C) <= R' + k0 |E|,   R' = R (1 + 1.07e-3).
+// Since 2 k0 R' |E| <= alpha R'^2 + (k0^2 / alpha) |E|^2 for any alpha > 0,
+//     (R' + k0 |E|)^2 <= R'^2 (1 + alpha) + k0^2 (1 + 1/alpha) |E|^2.
+// The device rejects the group iff  a * (|E|^2 (1 - beta) - q) > (ray.E)^2,  which in exact
+// arithmetic means dist(line, C)^2 > q + beta |E|^2.  With alpha = 1/16, q = R'^2 (1 + alpha)
+// rounded up, and beta = 2.2e-5 >= k0^2 * 17 (1.95e-5) + 16u (the f32 error of evaluating the
+// test itself, relative to a |E|^2: 9u in (ray.E)^2, 7u in the left side), a rejected group
+// holds no sphere the reference could accept.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "rt_host.h"
+
+namespace rtamd {
+
+namespace {
+
+const double CULL_ALPHA = 1.0 / 16.0;
+const double CULL_K0 = 1.07e-3;  // device side: beta = 2.2e-5 in rt_traverse.h
+
+float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafter(f, INFINITY);
+    return std::nextafter(f, INFINITY);
+}
+
+// {C, q} bounding entries [b, e) of v
+void bound(const std::vector<LeafSphere>& v, size_t b, size_t e, float out[4]) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = b; i < e; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], (double)v[i].c[a] - std::fabs((double)v[i].r));
+            hi[a] = std::max(hi[a], (double)v[i].c[a] + std::fabs((double)v[i].r));
+        }
+    float C[3];
+    for (int a = 0; a < 3; ++a) C[a] = (float)(0.5 * (lo[a] + hi[a]));
+    double R = 0.0;
+    for (size_t i = b; i < e; ++i) {
+        double d2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            double d = (double)v[i].c[a] - (double)C[a];
+            d2 += d * d;
+        }
+        R = std::max(R, std::sqrt(d2) + std::fabs((double)v[i].r));
+    }
+    const double Rp = R * (1.0 + CULL_K0) * (1.0 + 1e-6);
+    out[0] = C[0]; out[1] = C[1]; out[2] = C[2];
+    out[3] = round_up(Rp * Rp * (1.0 + CULL_ALPHA));
+    if (!(out[3] == out[3]) || !(R == R)) out[3] = INFINITY;  // never cull what cannot be bounded
+}
+
+// Median splits on the longest axis of the centres; the left part is a multiple of `g`
+// entries so that groups of g consecutive entries never straddle a split.
+void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
+    const size_t n = e - b;
+    if (n <= 8) return;
+    const size_t g = n > 4096 ? 2048 : (n > 256 ? 128 : 8);
+    size_t m = ((n / 2 + g - 1) / g) * g;
+    if (m >= n) m = n - (n % g ? n % g : g);
+    if (m == 0 || m >= n) return;
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = v[b].c[a];
+    for (size_t i = b; i < e; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], v[i].c[a]);
+            hi[a] = std::max(hi[a], v[i].c[a]);
+        }
+    int ax = 0;
+    for (int a = 1; a < 3; ++a)
+        if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+    auto key = [ax](const LeafSphere& s) { return s.c[ax] == s.c[ax] ? s.c[ax] : INFINITY; };  // total order
+    std::nth_element(v.begin() + b, v.begin() + b + m, v.begin() + e, [&key](const LeafSphere& x, const LeafSphere& y) {
+        const float kx = key(x), ky = key(y);
+        if (kx != ky) return kx < ky;
+        return x.pos < y.pos;  // deterministic
+    });
+    order(v, b, b + m);
+    order(v, b + m, e);
+}
+
+}  // namespace
+
+void cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& clus, std::vector<float>& sup) {
+    if (v.empty()) return;
+    order(v, 0, v.size());
+    const size_t n = v.size();
+    while (v.size() % 8) v.push_back(v.back());  // padding: copies change nothing (same distance, same position)
+    const size_t nclus = v.size() / 8;
+    for (size_t c = 0; c < nclus; ++c) {
+        float rec[4];
+        bound(v, c * 8, std::min(n, c * 8 + 8), rec);
+        clus.insert(clus.end(), rec, rec + 4);
+    }
+    for (size_t s = 0; s * 16 < nclus; ++s) {
+        float rec[4];
+        bound(v, s * 128, std::min(n, s * 128 + 128), rec);
+        sup.insert(sup.end(), rec, rec + 4);
+    }
+}
+
+}  // namespace rtamd

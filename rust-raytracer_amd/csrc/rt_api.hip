@@ -72,6 +72,7 @@ struct rt_scene {
     DevBuf<uint4> nodes, cone_items, poly_items;
     DevBuf<float4> sph;
     DevBuf<uint2> sph_id;
+    DevBuf<float> clus, sup;
     DevBuf<float4> cones, vpos, vnrm, surfaces, lights;
     DevBuf<uint32_t> prim_surface;
     DevScene dev{};
@@ -199,6 +200,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     memcpy(nodes.data(), sc->tree.nodes.data(), sc->tree.nodes.size() * sizeof(rt_kd_node));
     std::vector<float4> sph;
     std::vector<uint2> sph_id;
+    std::vector<float> clus, sup;  // 4 floats per record
     std::vector<uint4> cone_items, poly_items;
     for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
         const rt_kd_node& n = sc->tree.nodes[ni];
@@ -208,27 +210,28 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             continue;
         }
         const uint32_t s0 = (uint32_t)sph.size(), c0 = (uint32_t)cone_items.size(), p0 = (uint32_t)poly_items.size();
-        uint32_t ns = 0;
+        const uint32_t u0 = (uint32_t)(sup.size() / 4);
+        std::vector<LeafSphere> ls;
         for (uint32_t k = 0; k < n.over; ++k) {
             const uint32_t prim = sc->tree.refs[n.under + k];
             const rt_primitive& p = sd.primitives[prim];
             if (p.kind == RT_KIND_SPHERE) {
                 const rt_sphere& s = sd.spheres[p.index];
-                sph.push_back(make_float4(s.center[0], s.center[1], s.center[2], s.radius * s.radius));  // src/sphere.rs:53
-                sph_id.push_back(make_uint2(prim, k));
-                ++ns;
+                ls.push_back(LeafSphere{{s.center[0], s.center[1], s.center[2]}, s.radius, prim, k});
             } else if (p.kind == RT_KIND_CONE) {
                 cone_items.push_back(make_uint4(prim, k, p.index, 0));
             } else {
                 poly_items.push_back(make_uint4(prim, k, sd.polygons[p.index].first_vertex, sd.polygons[p.index].vertex_count));
             }
         }
-        while (sph.size() % 4) {  // pad: the sphere loop reads entries four at a time (and skips k >= count)
-            sph.push_back(make_float4(0.0f, 0.0f, 0.0f, -1.0f));
-            sph_id.push_back(make_uint2(0xffffffffu, 0xffffffffu));
+        const uint32_t ns = (uint32_t)ls.size();
+        cluster_spheres(ls, clus, sup);  // spatial order, padded to 8, bounding records appended
+        for (const LeafSphere& e : ls) {
+            sph.push_back(make_float4(e.c[0], e.c[1], e.c[2], e.r * e.r));  // src/sphere.rs:53
+            sph_id.push_back(make_uint2(e.prim, e.pos));
         }
         nodes[ni * 4 + 2] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
-        nodes[ni * 4 + 3] = make_uint4(p0, (uint32_t)poly_items.size() - p0, 0, 0);
+        nodes[ni * 4 + 3] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, 0);
     }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;
@@ -255,6 +258,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     RT_HIP(ctx, sc->nodes.upload(nodes));
     RT_HIP(ctx, sc->sph.upload(sph));
     RT_HIP(ctx, sc->sph_id.upload(sph_id));
+    for (int k = 0; k < 16; ++k) clus.push_back(0.0f);  // the walk reads cluster records four at a time
+    RT_HIP(ctx, sc->clus.upload(clus));
+    RT_HIP(ctx, sc->sup.upload(sup));
     RT_HIP(ctx, sc->cone_items.upload(cone_items));
     RT_HIP(ctx, sc->poly_items.upload(poly_items));
     RT_HIP(ctx, sc->cones.upload(cones));
@@ -268,6 +274,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.nodes = sc->nodes.p;
     d.sph = sc->sph.p;
     d.sph_id = sc->sph_id.p;
+    d.clus = (const float4*)sc->clus.p;
+    d.sup = (const float4*)sc->sup.p;
     d.cone_items = sc->cone_items.p;
     d.poly_items = sc->poly_items.p;
     d.cones = sc->cones.p;
@@ -368,6 +376,7 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
 
     const bool fast = opt->fp_mode == RT_FP_FAST;
     const bool work = opt->collect_work != 0;
+    const bool cull = opt->exhaustive_leaves == 0;
     const uint32_t n_lights = scene->dev.n_lights;
     size_t cap = std::max<size_t>(ctx->pool_cap, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
     size_t scap = std::max<size_t>(ctx->shadow_cap, std::max<size_t>((size_t)n_slots * n_lights, 1u << 16));
@@ -412,9 +421,9 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
             std::max<uint64_t>(1, ((uint64_t)n_slots * n_lights + RT_BLOCK - 1) / RT_BLOCK), 65536);
         for (uint32_t level = 0; level <= opt->max_depth; ++level) {
             const uint32_t g = level == 0 ? grid0 : gridn;
-            RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, g, st) : rt_exact::launch_intersect(A, level, work, g, st));
+            RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
             if (n_lights)
-                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, grids, st) : rt_exact::launch_shadow(A, level, work, grids, st));
+                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, cull, grids, st) : rt_exact::launch_shadow(A, level, work, cull, grids, st));
             RT_HIP(ctx, fast ? rt_fast::launch_shade(A, level, work, g, st) : rt_exact::launch_shade(A, level, work, g, st));
         }
         RT_HIP(ctx, hipEventRecord(ctx->ev[1], st));
@@ -507,11 +516,12 @@ extern "C" int rt_deinterleave_device(rt_context* ctx, uint32_t width, uint32_t 
     return RT_OK;
 }
 
-extern "C" int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32_t fp_mode, uint64_t n,
+extern "C" int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32_t fp_mode_flags, uint64_t n,
                                   const float* src, const float* ray, const float* near, const uint32_t* ignore,
                                   uint32_t* out_prim, float* out_dist, float* out_normal) {
     if (!ctx || !scene || !src || !ray || !near || !ignore || !out_prim || !out_dist || !out_normal)
         return fail(ctx, RT_ERR_INVALID, "null argument");
+    const uint32_t fp_mode = fp_mode_flags & ~RT_DEBUG_EXHAUSTIVE;
     if (fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown fp_mode");
     if (n == 0) return RT_OK;
     for (uint64_t i = 0; i < n; ++i)
@@ -534,9 +544,9 @@ extern "C" int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32
     RT_HIP(ctx, hipMemcpy(d_near.p, near, n * 4, hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(d_ign.p, ignore, n * 4, hipMemcpyHostToDevice));
     if (fp_mode == RT_FP_FAST)
-        RT_HIP(ctx, rt_fast::launch_debug_intersect(scene->dev, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
+        RT_HIP(ctx, rt_fast::launch_debug_intersect(scene->dev, (fp_mode_flags & RT_DEBUG_EXHAUSTIVE) == 0, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
     else
-        RT_HIP(ctx, rt_exact::launch_debug_intersect(scene->dev, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
+        RT_HIP(ctx, rt_exact::launch_debug_intersect(scene->dev, (fp_mode_flags & RT_DEBUG_EXHAUSTIVE) == 0, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
     RT_HIP(ctx, hipDeviceSynchronize());
     RT_HIP(ctx, hipMemcpy(out_prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
     RT_HIP(ctx, hipMemcpy(out_dist, d_dist.p, n * 4, hipMemcpyDeviceToHost));

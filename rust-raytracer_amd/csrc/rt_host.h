@@ -18,6 +18,16 @@ struct HostTree {
 int prim_box(const rt_scene_desc& d, uint32_t prim, float corner[3], float extent[3]);
 int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err);
 
+// leaf_cluster.cpp: bounding-sphere groups over the spheres of one leaf
+struct LeafSphere {
+    float c[3];
+    float r;
+    uint32_t prim, pos;  // primitive id, position in the leaf's list
+};
+// Re-orders `v` spatially, pads it to a multiple of 8 entries, and appends one {centre, q}
+// record per 8 entries to `clus` and per 128 entries to `sup` (4 floats each).
+void cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& clus, std::vector<float>& sup);
+
 // Validates counts, pointers and every index in a scene description.
 int validate_desc(const rt_scene_desc& d, std::string& err);
 

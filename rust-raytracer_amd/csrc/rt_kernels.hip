@@ -120,7 +120,7 @@ RT_DEV bool fetch_ray(const FrameArgs& A, uint32_t i, uint32_t node, Ray& r) {
 // ---------------------------------------------------------------------------------------
 // k_intersect: closest hit of every ray of one level + its shadow rays
 // ---------------------------------------------------------------------------------------
-template <bool LEVEL0, class Ctr>
+template <bool LEVEL0, bool CULL, class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t le
         Hit hit;
         hit.dist = 0.0f; hit.prim = NO_PRIM; hit.n = f3(0, 0, 0);
         if (active) {
-            const bool ok = kd_traverse_closest(S, ray.src, ray.dir, ray.near, ray.ignore, hit, lds_stack, ctr);
+            const bool ok = kd_traverse_closest<CULL>(S, ray.src, ray.dir, ray.near, ray.ignore, hit, lds_stack, ctr);
             if (!ok) hit.prim = NO_PRIM;
             A.hit_a[node] = make_float4(hit.n.x, hit.n.y, hit.n.z, hit.dist);
             A.hit_p[node] = hit.prim;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t le
 // a full closest-hit query ignoring the surface's own primitive, blocked iff its distance
 // <= the light's distance.
 // ---------------------------------------------------------------------------------------
-template <class Ctr>
+template <bool CULL, class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(FrameArgs A, uint32_t level
         const float4 sd = A.sray_d[i];
         Hit blocker;
         bool blocked = false;
-        if (kd_traverse_closest(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
+        if (kd_traverse_closest<CULL>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
                                 lds_stack, ctr))
             blocked = blocker.dist <= so.w;
         A.sray_blocked[i] = blocked ? 1u : 0u;
@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_deinterleave(DeinterleaveArgs D) {
 // ---------------------------------------------------------------------------------------
 // diagnostics: device routines run one row per lane (parity tests)
 // ---------------------------------------------------------------------------------------
+template <bool CULL>
 __global__ void __launch_bounds__(RT_BLOCK) k_debug_intersect(DevScene S, uint64_t n, const float* src, const float* ray,
                                                               const float* near, const uint32_t* ignore,
                                                               uint32_t* out_prim, float* out_dist, float* out_normal) {
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_intersect(DevScene S, uint64
     if (i >= n) return;
     NoCounters ctr;
     Hit hit;
-    const bool ok = kd_traverse_closest(S, f3(src[3 * i], src[3 * i + 1], src[3 * i + 2]),
+    const bool ok = kd_traverse_closest<CULL>(S, f3(src[3 * i], src[3 * i + 1], src[3 * i + 2]),
                                         f3(ray[3 * i], ray[3 * i + 1], ray[3 * i + 2]), near[i], ignore[i], hit,
                                         lds_stack, ctr);
     out_prim[i] = ok ? hit.prim : NO_PRIM;
@@ -489,10 +490,12 @@ static size_t stack_bytes(const DevScene& S) { return (size_t)S.stack_depth * RT
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
 hipError_t init_kernels() {
     const int max_lds = 160 * 1024;
-    const void* fns[] = {(const void*)k_intersect<true, WorkCounters>, (const void*)k_intersect<true, NoCounters>,
-                         (const void*)k_intersect<false, WorkCounters>, (const void*)k_intersect<false, NoCounters>,
-                         (const void*)k_shadow<WorkCounters>, (const void*)k_shadow<NoCounters>,
-                         (const void*)k_debug_intersect};
+    const void* fns[] = {(const void*)k_intersect<true, false, WorkCounters>, (const void*)k_intersect<true, false, NoCounters>,
+                         (const void*)k_intersect<true, true, NoCounters>, (const void*)k_intersect<false, false, WorkCounters>,
+                         (const void*)k_intersect<false, false, NoCounters>, (const void*)k_intersect<false, true, NoCounters>,
+                         (const void*)k_shadow<false, WorkCounters>, (const void*)k_shadow<false, NoCounters>,
+                         (const void*)k_shadow<true, NoCounters>, (const void*)k_debug_intersect<false>,
+                         (const void*)k_debug_intersect<true>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         if (e != hipSuccess) return e;
@@ -500,22 +503,29 @@ hipError_t init_kernels() {
     return hipSuccess;
 }
 
-hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
+// `work` selects the instrumented kernels, which always walk leaves exhaustively so that the
+// counters are the reference's work; otherwise `cull` selects the culled leaf walk.
+hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
+    const dim3 g(grid), b(RT_BLOCK);
     if (level == 0) {
-        if (work) hipLaunchKernelGGL((k_intersect<true, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
-        else hipLaunchKernelGGL((k_intersect<true, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        if (work) hipLaunchKernelGGL((k_intersect<true, false, WorkCounters>), g, b, lds, st, A, level);
+        else if (cull) hipLaunchKernelGGL((k_intersect<true, true, NoCounters>), g, b, lds, st, A, level);
+        else hipLaunchKernelGGL((k_intersect<true, false, NoCounters>), g, b, lds, st, A, level);
     } else {
-        if (work) hipLaunchKernelGGL((k_intersect<false, WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
-        else hipLaunchKernelGGL((k_intersect<false, NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+        if (work) hipLaunchKernelGGL((k_intersect<false, false, WorkCounters>), g, b, lds, st, A, level);
+        else if (cull) hipLaunchKernelGGL((k_intersect<false, true, NoCounters>), g, b, lds, st, A, level);
+        else hipLaunchKernelGGL((k_intersect<false, false, NoCounters>), g, b, lds, st, A, level);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
+hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
-    if (work) hipLaunchKernelGGL((k_shadow<WorkCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
-    else hipLaunchKernelGGL((k_shadow<NoCounters>), dim3(grid), dim3(RT_BLOCK), lds, st, A, level);
+    const dim3 g(grid), b(RT_BLOCK);
+    if (work) hipLaunchKernelGGL((k_shadow<false, WorkCounters>), g, b, lds, st, A, level);
+    else if (cull) hipLaunchKernelGGL((k_shadow<true, NoCounters>), g, b, lds, st, A, level);
+    else hipLaunchKernelGGL((k_shadow<false, NoCounters>), g, b, lds, st, A, level);
     return hipGetLastError();
 }
 
@@ -542,11 +552,12 @@ hipError_t launch_deinterleave(const DeinterleaveArgs& D, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_debug_intersect(const DevScene& S, uint64_t n, const float* src, const float* ray, const float* near,
-                                  const uint32_t* ignore, uint32_t* out_prim, float* out_dist, float* out_normal,
-                                  hipStream_t st) {
-    hipLaunchKernelGGL(k_debug_intersect, dim3((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK),
-                       stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, const float* src, const float* ray,
+                                  const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist,
+                                  float* out_normal, hipStream_t st) {
+    const dim3 g((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), b(RT_BLOCK);
+    if (cull) hipLaunchKernelGGL(k_debug_intersect<true>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    else hipLaunchKernelGGL(k_debug_intersect<false>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     return hipGetLastError();
 }
 

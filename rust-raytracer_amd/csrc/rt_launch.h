@@ -12,11 +12,13 @@ namespace rtamd {
 // Scene as the kernels see it (all device pointers).
 struct DevScene {
     // 4 x uint4 per node (64 B): {bmin, plane} {bmax, axis}; interior: {under, over, -, -} {-};
-    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, -, -}
+    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, first super-cluster, -}
     const uint4* nodes;
     // Leaf primitive lists, one run per kind and leaf, each in the builder's list order.
-    const float4* sph;         // sphere runs: {centre, r*r}; every run padded to a multiple of 4 entries
+    const float4* sph;         // sphere runs: {centre, r*r}; every run padded to a multiple of 8 entries
     const uint2* sph_id;       // parallel to sph: {primitive, position in the leaf's list}
+    const float4* clus;        // one bounding record {centre, q} per 8 sphere entries (entry index / 8)
+    const float4* sup;         // one bounding record per 16 clusters of a run, from the leaf's sup_first
     const uint4* cone_items;   // {primitive, position in the leaf's list, cone index, -}
     const uint4* poly_items;   // {primitive, position in the leaf's list, first vertex, vertex count}
     const float4* cones;       // 2 per cone: {base, base radius} {apex, apex radius}
@@ -78,12 +80,12 @@ struct DeinterleaveArgs {
 #define RT_DECLARE_LAUNCHERS(NS)                                                                                     \
     namespace NS {                                                                                                   \
     hipError_t init_kernels();                                                                                       \
-    hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st); \
-    hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st);   \
+    hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st); \
+    hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st); \
     hipError_t launch_shade(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st);    \
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
-    hipError_t launch_debug_intersect(const rtamd::DevScene& S, uint64_t n, const float* src, const float* ray,      \
+    hipError_t launch_debug_intersect(const rtamd::DevScene& S, bool cull, uint64_t n, const float* src, const float* ray, \
                                       const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist, \
                                       float* out_normal, hipStream_t st);                                            \
     hipError_t launch_debug_eval(uint32_t op, uint64_t n, const float* in, uint32_t is, float* out, uint32_t os,     \

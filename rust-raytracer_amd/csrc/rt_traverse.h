@@ -202,10 +202,92 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
     }
 }
 
-template <bool U, class Ctr>
+// ---------------------------------------------------------------------------------------
+// Culled walk of a big sphere run.  The run's entries are grouped 8 to a cluster and 16
+// clusters to a super-cluster, each with a bounding record {C, q} built on the host
+// (leaf_cluster.cpp, which also derives the bound).  A group is skipped only when NO lane of
+// the wave can be accepted by the reference's test for ANY sphere inside it:
+//     a * (|E|^2 * (1 - beta) - q) > (ray . E)^2,   E = src - C,  beta = 2.2e-5,
+// which implies dist(line, C)^2 > q + beta' |E|^2 >= the widest the reference's f32 evaluation
+// of b*b - 4ac can stretch any enclosed sphere (q carries the bounding radius with its margin).  Skipping changes no result: every skipped
+// sphere would have been rejected.  This test is not part of the reference's arithmetic, so
+// it may use FMA.
+// ---------------------------------------------------------------------------------------
+constexpr float CULL_ONE_MINUS_BETA = 0.999978f;  // 1 - 2.2e-5
+
+RT_DEV bool bound_may_hit(float cx, float cy, float cz, float q, F3 src, F3 ray, float a) {
+    const float ex = src.x - cx, ey = src.y - cy, ez = src.z - cz;
+    const float d = __builtin_fmaf(ray.z, ez, __builtin_fmaf(ray.y, ey, ray.x * ex));
+    const float ee = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+    const float t = __builtin_fmaf(ee, CULL_ONE_MINUS_BETA, -q);
+    return !(a * t > d * d);  // NaN anywhere keeps the group
+}
+
+template <class Ctr>
+RT_DEV void leaf_spheres_culled(const DevScene& S, uint32_t first, uint32_t count, uint32_t sup_first, F3 src, F3 ray,
+                                float a, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef const __attribute__((address_space(4))) f32x16* cf16_ptr;
+    const uint32_t c0 = first >> 3;              // runs start on a multiple of 8 entries
+    const uint32_t nclus = (count + 7u) >> 3;
+    const uint32_t nsup = (nclus + 15u) >> 4;
+    for (uint32_t s = 0; s < nsup; ++s) {
+        if (nclus > 16u) {
+            const float4 sb = ld_f4<true>(S.sup, sup_first + s);
+            if (__ballot(bound_may_hit(sb.x, sb.y, sb.z, sb.w, src, ray, a)) == 0ull) continue;
+        }
+        const uint32_t cb = c0 + s * 16u;
+        const uint32_t ce = cb + 16u < c0 + nclus ? cb + 16u : c0 + nclus;
+        for (uint32_t c = cb; c < ce; c += 4) {
+            // four cluster records per 64-byte scalar load (the array is padded past its end)
+            const f32x16 q = *(cf16_ptr)(S.clus + c);
+            uint64_t live[4];
+            live[0] = __ballot(bound_may_hit(q[0], q[1], q[2], q[3], src, ray, a));
+            live[1] = __ballot(bound_may_hit(q[4], q[5], q[6], q[7], src, ray, a));
+            live[2] = __ballot(bound_may_hit(q[8], q[9], q[10], q[11], src, ray, a));
+            live[3] = __ballot(bound_may_hit(q[12], q[13], q[14], q[15], src, ray, a));
+            if ((live[0] | live[1] | live[2] | live[3]) == 0ull) continue;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (live[j] == 0ull || c + j >= ce) continue;
+                const uint32_t e0 = (c + j) * 8u;
+                const cf16_ptr blk = (cf16_ptr)(S.sph + e0);
+                const f32x16 lo = blk[0], hi = blk[1];
+                float d0, d1, d2, d3, d4, d5, d6, d7, k0, k1, k2, k3, k4, k5, k6, k7;
+                const bool m0 = sphere_quick(lo[0], lo[1], lo[2], lo[3], src, ray, a, d0, k0);
+                const bool m1 = sphere_quick(lo[4], lo[5], lo[6], lo[7], src, ray, a, d1, k1);
+                const bool m2 = sphere_quick(lo[8], lo[9], lo[10], lo[11], src, ray, a, d2, k2);
+                const bool m3 = sphere_quick(lo[12], lo[13], lo[14], lo[15], src, ray, a, d3, k3);
+                const bool m4 = sphere_quick(hi[0], hi[1], hi[2], hi[3], src, ray, a, d4, k4);
+                const bool m5 = sphere_quick(hi[4], hi[5], hi[6], hi[7], src, ray, a, d5, k5);
+                const bool m6 = sphere_quick(hi[8], hi[9], hi[10], hi[11], src, ray, a, d6, k6);
+                const bool m7 = sphere_quick(hi[12], hi[13], hi[14], hi[15], src, ray, a, d7, k7);
+                if ((__ballot(m0) | __ballot(m1) | __ballot(m2) | __ballot(m3) | __ballot(m4) | __ballot(m5) |
+                     __ballot(m6) | __ballot(m7)) != 0ull) {
+                    // padding entries are copies of the run's last sphere: same distance, same
+                    // list position, so accepting one again changes nothing
+                    if (m0) sphere_finish<true>(S, e0, d0, k0, a, near, ignore, lb, ctr);
+                    if (m1) sphere_finish<true>(S, e0 + 1, d1, k1, a, near, ignore, lb, ctr);
+                    if (m2) sphere_finish<true>(S, e0 + 2, d2, k2, a, near, ignore, lb, ctr);
+                    if (m3) sphere_finish<true>(S, e0 + 3, d3, k3, a, near, ignore, lb, ctr);
+                    if (m4) sphere_finish<true>(S, e0 + 4, d4, k4, a, near, ignore, lb, ctr);
+                    if (m5) sphere_finish<true>(S, e0 + 5, d5, k5, a, near, ignore, lb, ctr);
+                    if (m6) sphere_finish<true>(S, e0 + 6, d6, k6, a, near, ignore, lb, ctr);
+                    if (m7) sphere_finish<true>(S, e0 + 7, d7, k7, a, near, ignore, lb, ctr);
+                }
+            }
+        }
+    }
+}
+
+template <bool U, bool CULL, class Ctr>
 RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, float a, float near, uint32_t ignore,
                       LeafBest& lb, Ctr& ctr) {
-    if (q2.y) leaf_spheres<U>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
+    if constexpr (U && CULL) {
+        if (q2.y) leaf_spheres_culled(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr);
+    } else {
+        if (q2.y) leaf_spheres<U>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
+    }
     if (q2.w) leaf_cones<U>(S, q2.z, q2.w, src, ray, near, ignore, lb, ctr);
     if (q3.y) leaf_polygons<U>(S, q3.x, q3.y, src, ray, near, ignore, lb, ctr);
 }
@@ -234,7 +316,7 @@ RT_DEV bool unwind(const uint2* my_stack, uint32_t stride, uint32_t& sp, F3 src,
     return false;
 }
 
-template <class Ctr>
+template <bool CULL, class Ctr>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr) {
     RayInv ri;
@@ -292,13 +374,14 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                         // (read again inside the branch: these copies stay in scalar registers)
                         const uint4 u2 = make_uint4(__builtin_amdgcn_readfirstlane(q2.x), __builtin_amdgcn_readfirstlane(q2.y),
                                                     __builtin_amdgcn_readfirstlane(q2.z), __builtin_amdgcn_readfirstlane(q2.w));
-                        const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y), 0u, 0u);
-                        leaf_runs<true>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
+                        const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y),
+                                                    __builtin_amdgcn_readfirstlane(q3.z), 0u);
+                        leaf_runs<true, CULL>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
                         mine_done = true;
                     }
                 }
             } else {
-                leaf_runs<false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
+                leaf_runs<false, false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
             }
             r_hit = lb.have;
             if (lb.have) {

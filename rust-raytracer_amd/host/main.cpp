@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     }
     const rt_view* v = rt_parsed_view(ps);
     std::vector<uint8_t> img((size_t)v->width * v->height * 3);
-    rt_options o{max_depth, 0.003f, fast ? (uint32_t)RT_FP_FAST : (uint32_t)RT_FP_EXACT, 0, 1, 0};
+    rt_options o{max_depth, 0.003f, fast ? (uint32_t)RT_FP_FAST : (uint32_t)RT_FP_EXACT, 0, 1, 0, 0};
     rt_stats st{};
     if (rt_render(ctx, sc, v, &o, nullptr, img.data(), &st) != RT_OK) {
         fprintf(stderr, "Error: %s\n", rt_last_error(ctx));

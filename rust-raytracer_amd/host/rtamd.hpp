@@ -142,7 +142,7 @@ inline rt_stats render(const View& view, const Scene& scene, RenderTarget& targe
     check(rt_scene_create(ctx, &d, &sc));
     rt_view v{{view.from.x, view.from.y, view.from.z}, {view.at.x, view.at.y, view.at.z},
               {view.up.dx, view.up.dy, view.up.dz}, view.angle, view.hither, view.width, view.height};
-    rt_options o{rs.max_depth, rs.min_contribution, rs.fp_mode, 0, 1, 0};
+    rt_options o{rs.max_depth, rs.min_contribution, rs.fp_mode, 0, 1, 0, 0};
     rt_stats st{};
     int rc = rt_render(ctx, sc, &v, &o, target.f32(), target.u8(), &st);
     if (rc != RT_OK) rt_scene_destroy(sc);

@@ -51,6 +51,14 @@ def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, heig
     if work:
         for k in rtamd.WORK_NAMES:
             assert got[k] == octr[k], (k, got[k], octr[k])
+    # the default kernels (no counters; big leaves skip sphere groups their bounding sphere rules
+    # out) and the exhaustive leaf walk must both give the same bits and the same rays
+    for exhaustive in (False, True):
+        cf, cu, cst = sc.render(rtamd.RenderOptions(max_depth=depth, fp_mode=rtamd.FP_EXACT,
+                                                    exhaustive_leaves=exhaustive), width, height)
+        assert np.array_equal(bits(cf), bits(of_p)) and np.array_equal(cu, ou_p), exhaustive
+        for k in RAY_KEYS:
+            assert cst.as_dict()[k] == octr[k], (exhaustive, k)
     # exact mode vs libm powf (the reference's pow)
     any_diff, big_diff, _ = lsb_report(gu, ou_l)
     assert big_diff == 0.0 and any_diff <= 1e-3, (any_diff, big_diff)

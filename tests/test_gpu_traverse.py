@@ -49,10 +49,11 @@ def test_closest_hit_matches_oracle(rtamd, oracle, spd, gpu_ctx, name):
     rng = np.random.default_rng(7)
     src, d, near, ignore = make_rays(rng, 30000, lo, hi, o.info.n_prims)
     wp, wd, wn = o.intersect_rays(src, d, near, ignore)
-    gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
-    assert np.array_equal(gp, wp)
-    assert np.array_equal(bits(gd), bits(wd))
-    assert np.array_equal(bits(gn), bits(wn))
+    for flags in (0, rtamd.DEBUG_EXHAUSTIVE):
+        gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | flags)
+        assert np.array_equal(gp, wp)
+        assert np.array_equal(bits(gd), bits(wd))
+        assert np.array_equal(bits(gn), bits(wn))
     assert 0.05 < (wp != 0xFFFFFFFF).mean()
     fp, fd, _ = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST)
     assert (fp != wp).mean() < 2e-3
@@ -60,3 +61,58 @@ def test_closest_hit_matches_oracle(rtamd, oracle, spd, gpu_ctx, name):
     # grazing hits on distant spheres lose digits to cancellation in b*b - 4ac under any rounding change
     rel = np.abs(fd[same] - wd[same]) / np.maximum(np.abs(wd[same]), 1e-3)
     assert (rel > 2e-4).mean() < 1e-2 and rel.max() < 2e-2
+
+
+def sphere_cloud(rng, n, scale, offset):
+    """One floor polygon (which makes the reference's builder give up early and leave leaves of
+    thousands of spheres) under a cloud of spheres with radii spread over three decades."""
+    c = (rng.uniform(-1, 1, (n, 3)) * scale + offset).astype(np.float32)
+    r = (scale * 10.0 ** rng.uniform(-3.5, -0.8, n)).astype(np.float32)
+    lines = ["v", "from %g %g %g" % tuple(offset + scale * np.array([3.0, 3.0, 2.0])), "at %g %g %g" % tuple(offset),
+             "up 0 0 1", "angle 40", "hither %g" % (scale * 1e-3), "resolution 32 32", "l %g %g %g" % tuple(offset + 5 * scale),
+             "f 1 0.5 0.5 0.5 0.5 3 0 0", "p 4"]
+    for sx, sy in ((-30, -30), (30, -30), (30, 30), (-30, 30)):
+        lines.append("%.9g %.9g %.9g" % (offset[0] + sx * scale, offset[1] + sy * scale, offset[2] - 1.5 * scale))
+    for k in range(n):
+        lines.append("s %.9g %.9g %.9g %.9g" % (c[k, 0], c[k, 1], c[k, 2], r[k]))
+    return "\n".join(lines) + "\n", c, r
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, (0.0, 0.0, 0.0)), (1.0, (900.0, -700.0, 400.0)),
+                                          (1e-3, (0.5, 0.25, -0.125)), (300.0, (1e4, 1e4, 0.0))])
+def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset):
+    """Big leaves skip groups of spheres whose bounding sphere rules them out.  The skip must be
+    invisible: the same primitive, distance and normal as the exhaustive walk and the oracle,
+    bit for bit, also for grazing rays (aimed at sphere silhouettes to within a few ulps), rays
+    from far away, rays that are not unit length, and coordinates far from the origin where the
+    reference's f32 discriminant accepts rays that geometrically miss."""
+    rng = np.random.default_rng(11)
+    offset = np.array(offset, np.float64)
+    text, c, r = sphere_cloud(rng, 6000, scale, offset)
+    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    o = oracle.OracleScene(text, build_threads=4)
+    assert o.info.max_leaf > 1000  # the degenerate build this test is about
+    n = 40000
+    far = rng.choice([1.5, 4.0, 60.0, 3000.0], n)[:, None]
+    src = offset + rng.normal(size=(n, 3)) * scale * far
+    pick = rng.integers(0, len(c), n)
+    to_c = c[pick].astype(np.float64) - src
+    dist = np.linalg.norm(to_c, axis=1, keepdims=True)
+    side = np.cross(to_c, rng.normal(size=(n, 3)))
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    # aim at the silhouette (the tangent point's direction), nudged in and out by up to 1e-5 radii
+    graze = 1.0 + rng.choice([0.0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -0.5], n)[:, None]
+    tgt = c[pick] + side * r[pick, None] * graze
+    d = tgt - src
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d *= rng.choice([1.0, 1.0, 0.01, 250.0], n)[:, None]  # shadow rays are not unit length
+    src, d = src.astype(np.float32), d.astype(np.float32)
+    near = rng.choice(np.array([0.0, 1e-4], np.float32), n).astype(np.float32)
+    ignore = np.where(rng.random(n) < 0.3, pick + 1, 0xFFFFFFFF).astype(np.uint32)  # primitive 0 is the floor
+    wp, wd, wn = o.intersect_rays(src, d, near, ignore)
+    ep, ed, en = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_EXHAUSTIVE)
+    gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
+    assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
+    assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    hit = wp != 0xFFFFFFFF
+    assert 0.2 < (hit & (wp != 0)).mean() < 0.98  # both sphere hits and misses are exercised
