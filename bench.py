@@ -14,9 +14,13 @@ region; inputs are resident in HBM when it starts and the finished image stays i
 Rank 0 prints one JSON line.  Besides the contract fields it carries
   roofline      VALU roofline of the trace kernels (this path has no dense contraction
                 and its scene data is cache resident, so neither "mfma" nor "hbm" binds):
-                algorithmic FLOPs per frame (work counters x per-event coefficients)
-                / summed trace-kernel time per frame (HIP events on the launch stream),
-                against the 157.3 TFLOP/s f32 vector peak; the HBM view alongside.
+                FLOPs the kernels execute per frame (device work counters of one
+                instrumented frame x per-event coefficients) / summed trace-kernel time per
+                frame (HIP events on the launch stream), against the 157.3 TFLOP/s f32
+                vector peak; the HBM view alongside.  "reference_work" holds the counters
+                of the reference's own exhaustive leaf walk for the same frame (what the
+                CPU baseline executes); the device skips sphere groups it can prove the
+                reference would reject, so it executes less.
   cpu_baseline  the CPU oracle (a port of the reference's algorithm; the reference itself
                 is Rust and cannot be built here) timed on this host on a bounded sample
                 of rows of the same frame.
@@ -46,9 +50,12 @@ sys.path.insert(0, ROOT)
 FLOP = {"node_visits": 27, "interior_steps": 4, "sphere_tests": 26, "sphere_hits": 25, "cone_tests": 123,
         "cone_hits": 51, "poly_tests": 32, "poly_edge_loops": 12, "poly_edges": 15, "poly_hits": 92,
         "light_evals": 16, "shade_evals": 37, "surface_hits": 15, "rays_reflect": 20, "rays_refract": 31,
-        "rays_primary": 25}
+        "rays_primary": 25,
+        # bounding-sphere test of the culled leaf walk (rt_traverse.h bound_may_hit): 3 sub,
+        # 2 mul + 5 fma, 2 mul, 1 compare
+        "bound_tests": 18}
 BYTES = {"node_visits": 64, "sphere_tests": 16, "cone_tests": 32, "poly_edges": 24, "light_evals": 24,
-         "shade_evals": 36}
+         "shade_evals": 36, "bound_tests": 16}
 RAY_STATE_BYTES = 2 * 64   # one 32-byte ray record + one 32-byte node record, written then read
 FRAMEBUFFER_BYTES = 3      # u8 RGB per pixel
 PEAK_F32_TFLOPS = 157.3
@@ -148,12 +155,16 @@ def main():
     # ---- work counters for the roofline: one instrumented frame, outside the timed region
     wopt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world,
                                collect_work=True)
-    wst = scene.render_device(wopt, None, (image if world == 1 else mine).data_ptr(), stream)
-    work = wst.as_dict()
-    wvec = torch.tensor([float(work[k]) for k in sorted(work)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(wvec, op=dist.ReduceOp.SUM)
-    work = dict(zip(sorted(work), (float(x) for x in wvec.cpu().numpy())))
+    def counted(o):
+        w = scene.render_device(o, None, (image if world == 1 else mine).data_ptr(), stream).as_dict()
+        vec = torch.tensor([float(w[k]) for k in sorted(w)], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        return dict(zip(sorted(w), (float(x) for x in vec.cpu().numpy())))
+
+    work = counted(wopt)  # what the timed kernels execute
+    wopt.exhaustive_leaves = True
+    ref_work = counted(wopt)  # what the reference's leaf walk executes for the same frame
 
     if rank != 0:
         if world > 1:
@@ -201,12 +212,14 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(flops / trace_s / 1e12 / PEAK_F32_TFLOPS, 5),
             "traffic": None,
-            "algorithmic_flops_per_frame": flops,
-            "algorithmic_bytes_per_frame": abytes,
+            "executed_flops_per_frame": flops,
+            "executed_bytes_per_frame": abytes,
             "hbm_achieved_GBs": round(abytes / trace_s / 1e9, 3),
             "hbm_peak_GBs": PEAK_HBM_GBS,
             "hbm_frac": round(abytes / trace_s / 1e9 / PEAK_HBM_GBS, 6),
             "work": {k: int(v) for k, v in work.items()},
+            "reference_work": {k: int(ref_work[k]) for k in ("node_visits", "sphere_tests", "cone_tests", "poly_tests")},
+            "reference_flops_per_frame": sum(ref_work[k] * c for k, c in FLOP.items()),
         },
     }
 

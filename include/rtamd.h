@@ -124,8 +124,9 @@ typedef struct rt_options {
     uint32_t fp_mode;        /* RT_FP_* */
     uint32_t tile_rank;      /* this context renders 8x8 tiles t with t % tile_count == tile_rank */
     uint32_t tile_count;     /* 0 or 1 = whole image */
-    uint32_t collect_work;   /* nonzero: also count node visits / shape tests (slower kernels;
-                                implies exhaustive_leaves, so the counts are the reference's work) */
+    uint32_t collect_work;   /* nonzero: also count node visits / shape tests (slower kernels).  With
+                                exhaustive_leaves the counts are the reference's own work; without,
+                                they are what the device executed (rt_stats.work) */
     uint32_t exhaustive_leaves; /* nonzero: test every primitive of every visited leaf as the reference
                                 does; 0 (default): big leaves skip groups of spheres whose bounding
                                 sphere proves that the reference's test rejects them -- same image */
@@ -137,8 +138,11 @@ typedef struct rt_stats {
     /* work counters, filled when rt_options.collect_work != 0:
      * node_visits, interior_steps, sphere_tests, sphere_hits, cone_tests, cone_hits,
      * poly_tests, poly_edge_loops, poly_edges, poly_hits, light_evals, shade_evals,
-     * surface_hits */
-    uint64_t work[13];
+     * surface_hits; then, for the culled walk of big sphere runs (exhaustive_leaves == 0):
+     * bound_tests (bounding-sphere tests executed), bound_passes (those passed at the lowest
+     * level), lane_slots (64 x the bound + sphere tests a wave issued: tests / lane_slots is the
+     * fraction of lanes doing useful work in that walk). */
+    uint64_t work[16];
     uint64_t ray_nodes;   /* ray-tree nodes used in the device pool */
     uint32_t levels;      /* deepest bounce level that held a ray, + 1 */
     uint32_t retries;     /* times the ray pool was grown and the frame re-run */

@@ -28,6 +28,8 @@ NO_PRIM = 0xFFFFFFFF
 
 WORK_NAMES = ("node_visits", "interior_steps", "sphere_tests", "sphere_hits", "cone_tests", "cone_hits",
               "poly_tests", "poly_edge_loops", "poly_edges", "poly_hits", "light_evals", "shade_evals", "surface_hits")
+# extra counters of the culled leaf walk (rt_stats.work[13..])
+CULL_NAMES = ("bound_tests", "bound_passes", "lane_slots")
 
 OP_AABB, OP_SPHERE, OP_CONE, OP_POLYGON, OP_PHONG, OP_BLINN, OP_REFLECT, OP_REFRACT, OP_POW, OP_QUANTIZE = range(10)
 
@@ -115,7 +117,7 @@ class rt_options(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
-                ("rays_refract", C.c_uint64), ("work", C.c_uint64 * 13), ("ray_nodes", C.c_uint64),
+                ("rays_refract", C.c_uint64), ("work", C.c_uint64 * 16), ("ray_nodes", C.c_uint64),
                 ("levels", C.c_uint32), ("retries", C.c_uint32), ("ms_trace", C.c_double), ("ms_resolve", C.c_double),
                 ("ms_frame", C.c_double), ("ms_d2h", C.c_double)]
 
@@ -126,7 +128,7 @@ class rt_stats(C.Structure):
     def as_dict(self):
         d = {"rays_primary": self.rays_primary, "rays_shadow": self.rays_shadow, "rays_reflect": self.rays_reflect,
              "rays_refract": self.rays_refract}
-        d.update({n: int(self.work[i]) for i, n in enumerate(WORK_NAMES)})
+        d.update({n: int(self.work[i]) for i, n in enumerate(WORK_NAMES + CULL_NAMES)})
         return d
 
 

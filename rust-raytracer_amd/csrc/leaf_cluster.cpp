@@ -3,10 +3,10 @@
 // The reference walks every primitive of a leaf (src/space_partition.rs:348-385); when its
 // tree degenerates into leaves of thousands of spheres that walk is the whole cost.  The
 // device may skip a group of spheres when it can PROVE that the reference's test would reject
-// each of them for this ray.  Groups: 8 consecutive entries of the (spatially re-ordered)
-// sphere run form a cluster, 16 consecutive clusters a super-cluster; each gets a bounding
-// record {centre C, q}.  Re-ordering is free: list order only matters for ties, and every
-// entry keeps its list position for that.
+// each of them for this ray.  The (spatially re-ordered) sphere run is grouped 8 entries to a
+// level-1 record, 8 level-1 records to a level-2 record, and so on up to level 4; every record
+// is a bounding sphere {centre C, q} of all entries below it.  Re-ordering is free: list
+// order only matters for ties, and every entry keeps its list position for that.
 //
 // What the reference can accept.  With u = 2^-24, e = src - c, a = |ray|^2, Sphere::intersect
 // (src/sphere.rs:49-56) returns a hit only if fl(b*b - 4*a*c) >= 0.  Bounding the rounding of
@@ -25,6 +25,7 @@
 // holds no sphere the reference could accept.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "rt_host.h"
@@ -68,11 +69,11 @@ void bound(const std::vector<LeafSphere>& v, size_t b, size_t e, float out[4]) {
 }
 
 // Median splits on the longest axis of the centres; the left part is a multiple of `g`
-// entries so that groups of g consecutive entries never straddle a split.
+// entries (the largest group size below n) so that no group straddles a split.
 void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
     const size_t n = e - b;
     if (n <= 8) return;
-    const size_t g = n > 4096 ? 2048 : (n > 256 ? 128 : 8);
+    const size_t g = n > 4096 ? 4096 : (n > 512 ? 512 : (n > 64 ? 64 : 8));
     size_t m = ((n / 2 + g - 1) / g) * g;
     if (m >= n) m = n - (n % g ? n % g : g);
     if (m == 0 || m >= n) return;
@@ -98,22 +99,37 @@ void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
 
 }  // namespace
 
-void cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& clus, std::vector<float>& sup) {
-    if (v.empty()) return;
+// Block layout in `bnd` (4 floats per record, indices in records):
+//   [h]            header, as integers: {first level-2 record, first level-3, first level-4, top level}
+//   [h+1 ...]      level-1 records (one per 8 entries), then levels 2, 3, 4.
+// Record i of level L bounds records 8i .. 8i+7 of level L-1 (entries 8i .. 8i+7 for L = 1).
+// The top level is the lowest one with at most 16 records (level 4 if none is that small); the
+// device tests it linearly and descends from there.
+uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd) {
+    const uint32_t h = (uint32_t)(bnd.size() / 4);
+    if (v.empty()) return h;
     order(v, 0, v.size());
     const size_t n = v.size();
     while (v.size() % 8) v.push_back(v.back());  // padding: copies change nothing (same distance, same position)
-    const size_t nclus = v.size() / 8;
-    for (size_t c = 0; c < nclus; ++c) {
-        float rec[4];
-        bound(v, c * 8, std::min(n, c * 8 + 8), rec);
-        clus.insert(clus.end(), rec, rec + 4);
+    bnd.insert(bnd.end(), 4, 0.0f);
+    uint32_t first[5] = {0, h + 1, 0, 0, 0};
+    size_t count[5] = {0, 0, 0, 0, 0};
+    size_t span = 8;  // entries per record of the level
+    for (int L = 1; L <= 4; ++L, span *= 8) {
+        first[L] = (uint32_t)(bnd.size() / 4);
+        count[L] = (n + span - 1) / span;
+        for (size_t i = 0; i < count[L]; ++i) {
+            float rec[4];
+            bound(v, i * span, std::min(n, (i + 1) * span), rec);
+            bnd.insert(bnd.end(), rec, rec + 4);
+        }
     }
-    for (size_t s = 0; s * 16 < nclus; ++s) {
-        float rec[4];
-        bound(v, s * 128, std::min(n, s * 128 + 128), rec);
-        sup.insert(sup.end(), rec, rec + 4);
-    }
+    uint32_t top = 4;
+    for (int L = 4; L >= 1; --L)
+        if (count[L] <= 16) top = (uint32_t)L;
+    const uint32_t hdr[4] = {first[2], first[3], first[4], top};
+    memcpy(&bnd[(size_t)h * 4], hdr, sizeof(hdr));
+    return h;
 }
 
 }  // namespace rtamd

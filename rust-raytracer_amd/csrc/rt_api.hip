@@ -72,7 +72,7 @@ struct rt_scene {
     DevBuf<uint4> nodes, cone_items, poly_items;
     DevBuf<float4> sph;
     DevBuf<uint2> sph_id;
-    DevBuf<float> clus, sup;
+    DevBuf<float> bnd;
     DevBuf<float4> cones, vpos, vnrm, surfaces, lights;
     DevBuf<uint32_t> prim_surface;
     DevScene dev{};
@@ -143,7 +143,7 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         return fail(ctx, RT_ERR_UNSUPPORTED, std::string("librtamd is built for gfx950 only; device is ") + prop.gcnArchName);
     for (auto& e : ctx->ev) RT_HIP(ctx, hipEventCreate(&e));
     RT_HIP(ctx, ctx->levels.alloc(3 * RT_MAX_LEVELS + 1));
-    RT_HIP(ctx, ctx->counters.alloc(17));
+    RT_HIP(ctx, ctx->counters.alloc(20));
     return RT_OK;
 }
 
@@ -200,7 +200,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     memcpy(nodes.data(), sc->tree.nodes.data(), sc->tree.nodes.size() * sizeof(rt_kd_node));
     std::vector<float4> sph;
     std::vector<uint2> sph_id;
-    std::vector<float> clus, sup;  // 4 floats per record
+    std::vector<float> bnd;  // 4 floats per record
     std::vector<uint4> cone_items, poly_items;
     for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
         const rt_kd_node& n = sc->tree.nodes[ni];
@@ -210,7 +210,6 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             continue;
         }
         const uint32_t s0 = (uint32_t)sph.size(), c0 = (uint32_t)cone_items.size(), p0 = (uint32_t)poly_items.size();
-        const uint32_t u0 = (uint32_t)(sup.size() / 4);
         std::vector<LeafSphere> ls;
         for (uint32_t k = 0; k < n.over; ++k) {
             const uint32_t prim = sc->tree.refs[n.under + k];
@@ -225,7 +224,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             }
         }
         const uint32_t ns = (uint32_t)ls.size();
-        cluster_spheres(ls, clus, sup);  // spatial order, padded to 8, bounding records appended
+        const uint32_t u0 = cluster_spheres(ls, bnd);  // spatial order, padded to 8, bounding records appended
         for (const LeafSphere& e : ls) {
             sph.push_back(make_float4(e.c[0], e.c[1], e.c[2], e.r * e.r));  // src/sphere.rs:53
             sph_id.push_back(make_uint2(e.prim, e.pos));
@@ -258,9 +257,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     RT_HIP(ctx, sc->nodes.upload(nodes));
     RT_HIP(ctx, sc->sph.upload(sph));
     RT_HIP(ctx, sc->sph_id.upload(sph_id));
-    for (int k = 0; k < 16; ++k) clus.push_back(0.0f);  // the walk reads cluster records four at a time
-    RT_HIP(ctx, sc->clus.upload(clus));
-    RT_HIP(ctx, sc->sup.upload(sup));
+    bnd.insert(bnd.end(), 8 * 4, 0.0f);  // the walk reads bounding records eight at a time
+    RT_HIP(ctx, sc->bnd.upload(bnd));
     RT_HIP(ctx, sc->cone_items.upload(cone_items));
     RT_HIP(ctx, sc->poly_items.upload(poly_items));
     RT_HIP(ctx, sc->cones.upload(cones));
@@ -274,8 +272,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.nodes = sc->nodes.p;
     d.sph = sc->sph.p;
     d.sph_id = sc->sph_id.p;
-    d.clus = (const float4*)sc->clus.p;
-    d.sup = (const float4*)sc->sup.p;
+    d.bnd = (const float4*)sc->bnd.p;
     d.cone_items = sc->cone_items.p;
     d.poly_items = sc->poly_items.p;
     d.cones = sc->cones.p;
@@ -288,7 +285,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
     memcpy(d.bg, sd.background, sizeof(d.bg));
     // the per-lane traversal stack lives in LDS: depth * 8 B * RT_BLOCK lanes per block
-    if ((size_t)d.stack_depth * RT_BLOCK * sizeof(uint2) > 160 * 1024)
+    if ((size_t)d.stack_depth * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t) > 160 * 1024)
         return fail(ctx, RT_ERR_UNSUPPORTED, "space partition deeper than the device traversal stack (80 levels)");
     *out = sc.release();
     return RT_OK;
@@ -410,7 +407,7 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         A.counters = ctx->counters.p;
 
         RT_HIP(ctx, hipMemsetAsync(ctx->levels.p, 0, (3 * RT_MAX_LEVELS + 1) * sizeof(uint32_t), st));
-        RT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 17 * sizeof(unsigned long long), st));
+        RT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 20 * sizeof(unsigned long long), st));
         RT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
 
         const uint32_t grid0 = std::max<uint32_t>(1, (n_slots + RT_BLOCK - 1) / RT_BLOCK);
@@ -446,14 +443,14 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
             if (attempt >= 8) return fail(ctx, RT_ERR_CAPACITY, "ray pool still too small after 8 growth steps");
             continue;
         }
-        unsigned long long c[17];
+        unsigned long long c[20];
         RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         stats.rays_primary = n_primary;
         stats.rays_shadow = 0;
         for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += lv[2 * RT_MAX_LEVELS + l];
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
-        for (int k = 0; k < 13; ++k) stats.work[k] = c[4 + k];
+        for (int k = 0; k < 16; ++k) stats.work[k] = c[4 + k];
         stats.ray_nodes = n_slots;
         stats.levels = 1;
         for (uint32_t l = 1; l <= opt->max_depth; ++l) {

@@ -24,9 +24,9 @@ struct LeafSphere {
     float r;
     uint32_t prim, pos;  // primitive id, position in the leaf's list
 };
-// Re-orders `v` spatially, pads it to a multiple of 8 entries, and appends one {centre, q}
-// record per 8 entries to `clus` and per 128 entries to `sup` (4 floats each).
-void cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& clus, std::vector<float>& sup);
+// Re-orders `v` spatially, pads it to a multiple of 8 entries, and appends the leaf's block of
+// bounding records to `bnd` (4 floats each); returns the index of the block's header record.
+uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd);
 
 // Validates counts, pointers and every index in a scene description.
 int validate_desc(const rt_scene_desc& d, std::string& err);

@@ -42,7 +42,7 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 template <class Ctr>
 RT_DEV void flush_work(const FrameArgs& A, Ctr& ctr) {
     if constexpr (Ctr::kEnabled) {
-        for (int k = 0; k < 13; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const uint32_t s = wave_sum(ctr.c[k]);
             if (lane_id() == 0 && s) atomicAdd(&A.counters[4 + k], (unsigned long long)s);
         }
@@ -485,12 +485,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
 // ---------------------------------------------------------------------------------------
 // host-callable launchers (one set per namespace)
 // ---------------------------------------------------------------------------------------
-static size_t stack_bytes(const DevScene& S) { return (size_t)S.stack_depth * RT_BLOCK * sizeof(uint2); }
+// traversal stack + the per-lane words of the culled leaf walk
+static size_t stack_bytes(const DevScene& S) {
+    return (size_t)S.stack_depth * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t);
+}
 
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
 hipError_t init_kernels() {
     const int max_lds = 160 * 1024;
-    const void* fns[] = {(const void*)k_intersect<true, false, WorkCounters>, (const void*)k_intersect<true, false, NoCounters>,
+    const void* fns[] = {(const void*)k_intersect<true, true, WorkCounters>, (const void*)k_intersect<false, true, WorkCounters>,
+                         (const void*)k_shadow<true, WorkCounters>,
+                         (const void*)k_intersect<true, false, WorkCounters>, (const void*)k_intersect<true, false, NoCounters>,
                          (const void*)k_intersect<true, true, NoCounters>, (const void*)k_intersect<false, false, WorkCounters>,
                          (const void*)k_intersect<false, false, NoCounters>, (const void*)k_intersect<false, true, NoCounters>,
                          (const void*)k_shadow<false, WorkCounters>, (const void*)k_shadow<false, NoCounters>,
@@ -503,17 +508,18 @@ hipError_t init_kernels() {
     return hipSuccess;
 }
 
-// `work` selects the instrumented kernels, which always walk leaves exhaustively so that the
-// counters are the reference's work; otherwise `cull` selects the culled leaf walk.
+// `work` selects the instrumented kernels, `cull` the culled walk of big leaves.
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
     const dim3 g(grid), b(RT_BLOCK);
     if (level == 0) {
-        if (work) hipLaunchKernelGGL((k_intersect<true, false, WorkCounters>), g, b, lds, st, A, level);
+        if (work && cull) hipLaunchKernelGGL((k_intersect<true, true, WorkCounters>), g, b, lds, st, A, level);
+        else if (work) hipLaunchKernelGGL((k_intersect<true, false, WorkCounters>), g, b, lds, st, A, level);
         else if (cull) hipLaunchKernelGGL((k_intersect<true, true, NoCounters>), g, b, lds, st, A, level);
         else hipLaunchKernelGGL((k_intersect<true, false, NoCounters>), g, b, lds, st, A, level);
     } else {
-        if (work) hipLaunchKernelGGL((k_intersect<false, false, WorkCounters>), g, b, lds, st, A, level);
+        if (work && cull) hipLaunchKernelGGL((k_intersect<false, true, WorkCounters>), g, b, lds, st, A, level);
+        else if (work) hipLaunchKernelGGL((k_intersect<false, false, WorkCounters>), g, b, lds, st, A, level);
         else if (cull) hipLaunchKernelGGL((k_intersect<false, true, NoCounters>), g, b, lds, st, A, level);
         else hipLaunchKernelGGL((k_intersect<false, false, NoCounters>), g, b, lds, st, A, level);
     }
@@ -523,7 +529,8 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
     const dim3 g(grid), b(RT_BLOCK);
-    if (work) hipLaunchKernelGGL((k_shadow<false, WorkCounters>), g, b, lds, st, A, level);
+    if (work && cull) hipLaunchKernelGGL((k_shadow<true, WorkCounters>), g, b, lds, st, A, level);
+    else if (work) hipLaunchKernelGGL((k_shadow<false, WorkCounters>), g, b, lds, st, A, level);
     else if (cull) hipLaunchKernelGGL((k_shadow<true, NoCounters>), g, b, lds, st, A, level);
     else hipLaunchKernelGGL((k_shadow<false, NoCounters>), g, b, lds, st, A, level);
     return hipGetLastError();

@@ -6,19 +6,19 @@
 
 #define RT_BLOCK 256
 #define RT_MAX_LEVELS 64  // max_depth + 2 must fit
+#define RT_LANE_WORDS 16   // per-lane LDS words of the culled leaf walk, after the traversal stack
 
 namespace rtamd {
 
 // Scene as the kernels see it (all device pointers).
 struct DevScene {
     // 4 x uint4 per node (64 B): {bmin, plane} {bmax, axis}; interior: {under, over, -, -} {-};
-    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, first super-cluster, -}
+    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, header of the sphere run's bounding records, -}
     const uint4* nodes;
     // Leaf primitive lists, one run per kind and leaf, each in the builder's list order.
     const float4* sph;         // sphere runs: {centre, r*r}; every run padded to a multiple of 8 entries
     const uint2* sph_id;       // parallel to sph: {primitive, position in the leaf's list}
-    const float4* clus;        // one bounding record {centre, q} per 8 sphere entries (entry index / 8)
-    const float4* sup;         // one bounding record per 16 clusters of a run, from the leaf's sup_first
+    const float4* bnd;         // per sphere run: header + bounding records {centre, q}, 8-ary, up to 4 levels
     const uint4* cone_items;   // {primitive, position in the leaf's list, cone index, -}
     const uint4* poly_items;   // {primitive, position in the leaf's list, first vertex, vertex count}
     const float4* cones;       // 2 per cone: {base, base radius} {apex, apex radius}

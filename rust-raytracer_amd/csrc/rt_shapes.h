@@ -395,11 +395,14 @@ struct NoCounters {
     RT_DEV void light_evals(uint32_t) {}
     RT_DEV void shade_evals(uint32_t) {}
     RT_DEV void surface_hits(uint32_t) {}
+    RT_DEV void bound_tests(uint32_t) {}
+    RT_DEV void bound_passes(uint32_t) {}
+    RT_DEV void lane_slots(uint32_t) {}
 };
 
 struct WorkCounters {
     static constexpr bool kEnabled = true;
-    uint32_t c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RT_DEV void node_visits(uint32_t n) { c[0] += n; }
     RT_DEV void interior_steps(uint32_t n) { c[1] += n; }
     RT_DEV void sphere_tests(uint32_t n) { c[2] += n; }
@@ -413,6 +416,9 @@ struct WorkCounters {
     RT_DEV void light_evals(uint32_t n) { c[10] += n; }
     RT_DEV void shade_evals(uint32_t n) { c[11] += n; }
     RT_DEV void surface_hits(uint32_t n) { c[12] += n; }
+    RT_DEV void bound_tests(uint32_t n) { c[13] += n; }
+    RT_DEV void bound_passes(uint32_t n) { c[14] += n; }
+    RT_DEV void lane_slots(uint32_t n) { c[15] += n; }
 };
 
 }  // namespace RT_NS

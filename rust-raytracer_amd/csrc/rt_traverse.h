@@ -203,91 +203,152 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
 }
 
 // ---------------------------------------------------------------------------------------
-// Culled walk of a big sphere run.  The run's entries are grouped 8 to a cluster and 16
-// clusters to a super-cluster, each with a bounding record {C, q} built on the host
-// (leaf_cluster.cpp, which also derives the bound).  A group is skipped only when NO lane of
-// the wave can be accepted by the reference's test for ANY sphere inside it:
+// Culled walk of a big sphere run, one lane = one ray, no wave-wide coupling.  The run's
+// entries are grouped 8 to a level-1 record, 8 level-1 records to a level-2 record, ... up to
+// level 4; each record is a bounding sphere {C, q} built on the host (leaf_cluster.cpp, which
+// also derives the bound and the layout).  A group is skipped only when the reference's test
+// cannot accept ANY sphere inside it:
 //     a * (|E|^2 * (1 - beta) - q) > (ray . E)^2,   E = src - C,  beta = 2.2e-5,
 // which implies dist(line, C)^2 > q + beta' |E|^2 >= the widest the reference's f32 evaluation
-// of b*b - 4ac can stretch any enclosed sphere (q carries the bounding radius with its margin).  Skipping changes no result: every skipped
-// sphere would have been rejected.  This test is not part of the reference's arithmetic, so
-// it may use FMA.
+// of b*b - 4ac can stretch any enclosed sphere (q carries the bounding radius with its margin).
+// Skipping changes no result: every skipped sphere would have been rejected.  This test is not
+// part of the reference's arithmetic, so it may use FMA.
+//
+// The walk is split in two loops so that the lanes of a wave run the same code on different
+// data: first a depth-first descent whose only step is "test the 8 records of one group"
+// (pending sibling masks sit on a 3-entry per-lane stack in LDS), which queues {level-1 group,
+// mask of live records}; then the queue is drained, each step testing the 8 spheres of one
+// live level-1 record with the reference's own arithmetic.
 // ---------------------------------------------------------------------------------------
 constexpr float CULL_ONE_MINUS_BETA = 0.999978f;  // 1 - 2.2e-5
+constexpr uint32_t CULL_MIN_SPHERES = 24;         // shorter runs are walked entry by entry
+constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - 3;  // per-lane LDS words: 3 stack entries + the queue
 
-RT_DEV bool bound_may_hit(float cx, float cy, float cz, float q, F3 src, F3 ray, float a) {
-    const float ex = src.x - cx, ey = src.y - cy, ez = src.z - cz;
+RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 ray, float a) {
+    const float ex = src.x - rec.x, ey = src.y - rec.y, ez = src.z - rec.z;
     const float d = __builtin_fmaf(ray.z, ez, __builtin_fmaf(ray.y, ey, ray.x * ex));
     const float ee = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-    const float t = __builtin_fmaf(ee, CULL_ONE_MINUS_BETA, -q);
+    const float t = __builtin_fmaf(ee, CULL_ONE_MINUS_BETA, -rec.w);
     return !(a * t > d * d);  // NaN anywhere keeps the group
 }
 
+// Live mask of the records base[0..8), of which the first `valid` exist (the array is padded
+// so that all 8 loads are in bounds).
 template <class Ctr>
-RT_DEV void leaf_spheres_culled(const DevScene& S, uint32_t first, uint32_t count, uint32_t sup_first, F3 src, F3 ray,
-                                float a, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    typedef const __attribute__((address_space(4))) f32x16* cf16_ptr;
-    const uint32_t c0 = first >> 3;              // runs start on a multiple of 8 entries
-    const uint32_t nclus = (count + 7u) >> 3;
-    const uint32_t nsup = (nclus + 15u) >> 4;
-    for (uint32_t s = 0; s < nsup; ++s) {
-        if (nclus > 16u) {
-            const float4 sb = ld_f4<true>(S.sup, sup_first + s);
-            if (__ballot(bound_may_hit(sb.x, sb.y, sb.z, sb.w, src, ray, a)) == 0ull) continue;
-        }
-        const uint32_t cb = c0 + s * 16u;
-        const uint32_t ce = cb + 16u < c0 + nclus ? cb + 16u : c0 + nclus;
-        for (uint32_t c = cb; c < ce; c += 4) {
-            // four cluster records per 64-byte scalar load (the array is padded past its end)
-            const f32x16 q = *(cf16_ptr)(S.clus + c);
-            uint64_t live[4];
-            live[0] = __ballot(bound_may_hit(q[0], q[1], q[2], q[3], src, ray, a));
-            live[1] = __ballot(bound_may_hit(q[4], q[5], q[6], q[7], src, ray, a));
-            live[2] = __ballot(bound_may_hit(q[8], q[9], q[10], q[11], src, ray, a));
-            live[3] = __ballot(bound_may_hit(q[12], q[13], q[14], q[15], src, ray, a));
-            if ((live[0] | live[1] | live[2] | live[3]) == 0ull) continue;
+RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 ray, float a, Ctr& ctr) {
+    float4 r[8];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                if (live[j] == 0ull || c + j >= ce) continue;
-                const uint32_t e0 = (c + j) * 8u;
-                const cf16_ptr blk = (cf16_ptr)(S.sph + e0);
-                const f32x16 lo = blk[0], hi = blk[1];
-                float d0, d1, d2, d3, d4, d5, d6, d7, k0, k1, k2, k3, k4, k5, k6, k7;
-                const bool m0 = sphere_quick(lo[0], lo[1], lo[2], lo[3], src, ray, a, d0, k0);
-                const bool m1 = sphere_quick(lo[4], lo[5], lo[6], lo[7], src, ray, a, d1, k1);
-                const bool m2 = sphere_quick(lo[8], lo[9], lo[10], lo[11], src, ray, a, d2, k2);
-                const bool m3 = sphere_quick(lo[12], lo[13], lo[14], lo[15], src, ray, a, d3, k3);
-                const bool m4 = sphere_quick(hi[0], hi[1], hi[2], hi[3], src, ray, a, d4, k4);
-                const bool m5 = sphere_quick(hi[4], hi[5], hi[6], hi[7], src, ray, a, d5, k5);
-                const bool m6 = sphere_quick(hi[8], hi[9], hi[10], hi[11], src, ray, a, d6, k6);
-                const bool m7 = sphere_quick(hi[12], hi[13], hi[14], hi[15], src, ray, a, d7, k7);
-                if ((__ballot(m0) | __ballot(m1) | __ballot(m2) | __ballot(m3) | __ballot(m4) | __ballot(m5) |
-                     __ballot(m6) | __ballot(m7)) != 0ull) {
-                    // padding entries are copies of the run's last sphere: same distance, same
-                    // list position, so accepting one again changes nothing
-                    if (m0) sphere_finish<true>(S, e0, d0, k0, a, near, ignore, lb, ctr);
-                    if (m1) sphere_finish<true>(S, e0 + 1, d1, k1, a, near, ignore, lb, ctr);
-                    if (m2) sphere_finish<true>(S, e0 + 2, d2, k2, a, near, ignore, lb, ctr);
-                    if (m3) sphere_finish<true>(S, e0 + 3, d3, k3, a, near, ignore, lb, ctr);
-                    if (m4) sphere_finish<true>(S, e0 + 4, d4, k4, a, near, ignore, lb, ctr);
-                    if (m5) sphere_finish<true>(S, e0 + 5, d5, k5, a, near, ignore, lb, ctr);
-                    if (m6) sphere_finish<true>(S, e0 + 6, d6, k6, a, near, ignore, lb, ctr);
-                    if (m7) sphere_finish<true>(S, e0 + 7, d7, k7, a, near, ignore, lb, ctr);
-                }
-            }
+    for (int k = 0; k < 8; ++k) r[k] = base[k];
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m |= bound_may_hit(r[k], src, ray, a) ? (1u << k) : 0u;
+    ctr.bound_tests(8);
+    if constexpr (Ctr::kEnabled) {
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true)))
+            ctr.lane_slots(8 * 64);
+    }
+    return valid >= 8u ? m : (m & ((1u << valid) - 1u));
+}
+
+// The 8 spheres of entries e0 .. e0+7 (padding entries are copies of the run's last sphere:
+// same distance, same list position, so accepting one again changes nothing).
+template <class Ctr>
+RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, float near, uint32_t ignore, LeafBest& lb,
+                     Ctr& ctr) {
+    float4 s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = S.sph[e0 + k];
+    float d[8], c[8];
+    uint32_t pass = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        pass |= sphere_quick(s[k].x, s[k].y, s[k].z, s[k].w, src, ray, a, d[k], c[k]) ? (1u << k) : 0u;
+    ctr.sphere_tests(8);
+    if constexpr (Ctr::kEnabled) {
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true)))
+            ctr.lane_slots(8 * 64);
+    }
+    // Few lanes pass, and rarely more than one entry each: one pass of this loop finishes
+    // every lane's next candidate, instead of one divergent branch per entry.
+    while (pass != 0u) {
+        const uint32_t k = (uint32_t)__builtin_ctz(pass);
+        pass &= pass - 1u;
+        float dk = d[0], ck = c[0];
+#pragma unroll
+        for (uint32_t j = 1; j < 8; ++j) {
+            dk = k == j ? d[j] : dk;
+            ck = k == j ? c[j] : ck;
         }
+        sphere_finish<false>(S, e0 + k, dk, ck, a, near, ignore, lb, ctr);
     }
 }
 
-template <bool U, bool CULL, class Ctr>
+template <class Ctr>
+RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, float a,
+                              float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
+    const float4 hf = S.bnd[header];
+    const uint32_t off1 = header + 1u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
+                   off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w);
+    const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
+    auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : off4)); };
+    auto level_n = [&](uint32_t L) { return L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : n4)); };
+    uint32_t qn = 0;
+
+    auto drain = [&]() {
+        uint32_t g = 0, m = 0;
+        while (m != 0u || qn != 0u) {
+            if (m == 0u) {
+                --qn;
+                const uint32_t e = lq[(3u + qn) * stride];
+                g = e >> 8;
+                m = e & 0xffu;
+            }
+            const uint32_t k = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
+        }
+    };
+
+    const uint32_t n_top = level_n(top);
+    for (uint32_t g0 = 0; g0 * 8u < n_top; ++g0) {
+        uint32_t L = top, g = g0, sp = 0;
+        uint32_t m = expand8(S.bnd + level_off(L) + g * 8u, n_top - g * 8u, src, ray, a, ctr);
+        for (;;) {
+            if (L == 1u) {  // g is a level-1 group: queue its live records
+                if (m != 0u) {
+                    ctr.bound_passes((uint32_t)__builtin_popcount(m));
+                    lq[(3u + qn) * stride] = (g << 8) | m;
+                    ++qn;
+                    if (qn == LANE_QUEUE) drain();
+                }
+                m = 0u;
+            }
+            if (m == 0u) {
+                if (sp == 0u) break;
+                --sp;
+                const uint32_t e = lq[sp * stride];
+                L = e >> 30;
+                m = (e >> 22) & 0xffu;
+                g = e & 0x3fffffu;
+            }
+            const uint32_t k = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            if (m != 0u) {
+                lq[sp * stride] = (L << 30) | (m << 22) | g;
+                ++sp;
+            }
+            g = g * 8u + k;  // record g*8+k of level L = group of that index one level down
+            L -= 1u;
+            m = expand8(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, ray, a, ctr);
+        }
+    }
+    drain();
+}
+
+template <bool U, class Ctr>
 RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, float a, float near, uint32_t ignore,
                       LeafBest& lb, Ctr& ctr) {
-    if constexpr (U && CULL) {
-        if (q2.y) leaf_spheres_culled(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr);
-    } else {
-        if (q2.y) leaf_spheres<U>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
-    }
+    if (q2.y) leaf_spheres<U>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
     if (q2.w) leaf_cones<U>(S, q2.z, q2.w, src, ray, near, ignore, lb, ctr);
     if (q3.y) leaf_polygons<U>(S, q3.x, q3.y, src, ray, near, ignore, lb, ctr);
 }
@@ -326,6 +387,7 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     const float a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
     const uint32_t stride = blockDim.x;
     uint2* my_stack = stack + threadIdx.x;
+    uint32_t* lane_words = (uint32_t*)(stack + S.stack_depth * stride) + threadIdx.x;  // RT_LANE_WORDS per lane, same stride
     uint32_t sp = 0;
     uint32_t cur = 0;
     bool done = false;
@@ -366,6 +428,12 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
         if (at_leaf) {
             LeafBest lb;
             lb.init();
+            if constexpr (CULL) {
+                if (q2.y >= CULL_MIN_SPHERES) {  // big sphere run: this lane's own walk of its bounding records
+                    leaf_spheres_lane(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                    q2.y = 0u;
+                }
+            }
             if (q2.y + q2.w + q3.y >= BIG_LEAF) {
                 // all lanes standing on the same leaf walk it together, index wave-uniform
                 bool mine_done = false;
@@ -375,13 +443,13 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                         const uint4 u2 = make_uint4(__builtin_amdgcn_readfirstlane(q2.x), __builtin_amdgcn_readfirstlane(q2.y),
                                                     __builtin_amdgcn_readfirstlane(q2.z), __builtin_amdgcn_readfirstlane(q2.w));
                         const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y),
-                                                    __builtin_amdgcn_readfirstlane(q3.z), 0u);
-                        leaf_runs<true, CULL>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
+                                                    0u, 0u);
+                        leaf_runs<true>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
                         mine_done = true;
                     }
                 }
             } else {
-                leaf_runs<false, false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
+                leaf_runs<false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
             }
             r_hit = lb.have;
             if (lb.have) {

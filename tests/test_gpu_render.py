@@ -39,8 +39,8 @@ def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, heig
     of_p, ou_p, octr, _ = o.render(width, height, max_depth=depth, pow_mode=oracle.POW_PORTABLE, threads=8)
     _, ou_l, _, _ = o.render(width, height, max_depth=depth, pow_mode=oracle.POW_LIBM, threads=8, want_f32=False)
 
-    gf, gu, st = sc.render(rtamd.RenderOptions(max_depth=depth, fp_mode=rtamd.FP_EXACT, collect_work=work),
-                           width, height)
+    gf, gu, st = sc.render(rtamd.RenderOptions(max_depth=depth, fp_mode=rtamd.FP_EXACT, collect_work=work,
+                                               exhaustive_leaves=work), width, height)
     # exact mode: bit-identical f32 framebuffer and identical bytes vs the portable-pow oracle
     mism = np.argwhere(bits(gf) != bits(of_p))
     assert mism.size == 0, (len(mism), mism[:5], gf[tuple(mism[0][:2])], of_p[tuple(mism[0][:2])])
