@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "rt_host.h"
@@ -68,15 +69,20 @@ void bound(const std::vector<LeafSphere>& v, size_t b, size_t e, float out[4]) {
     if (!(out[3] == out[3]) || !(R == R)) out[3] = INFINITY;  // never cull what cannot be bounded
 }
 
-// Median splits on the longest axis of the centres; the left part is a multiple of `g`
-// entries (the largest group size below n) so that no group straddles a split.
+// Median splits on the longest axis of the centres.  Records group entries by absolute index
+// (8i .. 8i+7, 64i .. 64i+63, ...), so the split point is the multiple of the largest group
+// size that lies inside (b, e), nearest to the middle: no group straddles a split.
 void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
-    const size_t n = e - b;
-    if (n <= 8) return;
-    const size_t g = n > 4096 ? 4096 : (n > 512 ? 512 : (n > 64 ? 64 : 8));
-    size_t m = ((n / 2 + g - 1) / g) * g;
-    if (m >= n) m = n - (n % g ? n % g : g);
-    if (m == 0 || m >= n) return;
+    size_t m = 0;
+    for (size_t g : {(size_t)4096, (size_t)512, (size_t)64, (size_t)8}) {
+        const size_t lo = (b / g + 1) * g;  // first multiple of g above b
+        if (lo >= e) continue;
+        const size_t mid = (b + e) / 2;
+        m = std::max(lo, (mid + g / 2) / g * g);
+        while (m >= e) m -= g;
+        break;
+    }
+    if (m <= b || m >= e) return;
     float lo[3], hi[3];
     for (int a = 0; a < 3; ++a) lo[a] = hi[a] = v[b].c[a];
     for (size_t i = b; i < e; ++i)
@@ -88,13 +94,40 @@ void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
     for (int a = 1; a < 3; ++a)
         if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
     auto key = [ax](const LeafSphere& s) { return s.c[ax] == s.c[ax] ? s.c[ax] : INFINITY; };  // total order
-    std::nth_element(v.begin() + b, v.begin() + b + m, v.begin() + e, [&key](const LeafSphere& x, const LeafSphere& y) {
+    std::nth_element(v.begin() + b, v.begin() + m, v.begin() + e, [&key](const LeafSphere& x, const LeafSphere& y) {
         const float kx = key(x), ky = key(y);
         if (kx != ky) return kx < ky;
         return x.pos < y.pos;  // deterministic
     });
-    order(v, b, b + m);
-    order(v, b + m, e);
+    order(v, b, m);
+    order(v, m, e);
+}
+
+// Spheres of very different size make poor neighbours: one big sphere inflates the bound of
+// every group it sits in.  The run is therefore cut into segments of similar radius (largest
+// first, a new segment when the radius has halved), each padded to a multiple of 8 entries
+// with copies of its last sphere and ordered spatially on its own.
+void arrange(std::vector<LeafSphere>& v) {
+    static const float CLASS_RATIO = getenv("RT_CLASS_RATIO") ? (float)atof(getenv("RT_CLASS_RATIO")) : 0.0f;
+    auto size_of = [](const LeafSphere& s) { const float r = std::fabs(s.r); return r == r ? r : INFINITY; };
+    std::stable_sort(v.begin(), v.end(), [&](const LeafSphere& x, const LeafSphere& y) { return size_of(x) > size_of(y); });
+    std::vector<LeafSphere> out;
+    out.reserve(v.size() + 64);
+    size_t i = 0;
+    while (i < v.size()) {
+        const size_t b = out.size();
+        const float r0 = size_of(v[i]);
+        size_t j = i;
+        while (j < v.size() && (j - i < 8 || size_of(v[j]) >= CLASS_RATIO * r0)) ++j;
+        out.insert(out.end(), v.begin() + i, v.begin() + j);
+        while (out.size() % 8) {  // a copy never wins: same distance as its original, later position
+            out.push_back(out.back());
+            out.back().pos |= 0x80000000u;
+        }
+        order(out, b, out.size());
+        i = j;
+    }
+    v.swap(out);
 }
 
 }  // namespace
@@ -108,9 +141,8 @@ void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
 uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd) {
     const uint32_t h = (uint32_t)(bnd.size() / 4);
     if (v.empty()) return h;
-    order(v, 0, v.size());
-    const size_t n = v.size();
-    while (v.size() % 8) v.push_back(v.back());  // padding: copies change nothing (same distance, same position)
+    arrange(v);
+    const size_t n = v.size();  // a multiple of 8
     bnd.insert(bnd.end(), 4, 0.0f);
     uint32_t first[5] = {0, h + 1, 0, 0, 0};
     size_t count[5] = {0, 0, 0, 0, 0};

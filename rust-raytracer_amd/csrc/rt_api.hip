@@ -56,12 +56,16 @@ struct rt_context {
     DevBuf<uint2> node_sh;
     size_t shadow_cap = 0;
     DevBuf<uint4> node_kid;
-    DevBuf<uint32_t> levels;  // level_count | level_base | shadow_count (RT_MAX_LEVELS each) | overflow
+    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_base[RT_MAX_LEVELS + 1] | shadow_total | overflow
+    DevBuf<uint32_t> levels;
     DevBuf<unsigned long long> counters;
     size_t pool_cap = 0;
     DevBuf<float> out_f32;
     DevBuf<uint8_t> out_u8;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t shadow_stream = nullptr;  // shadow rays of a level run here, beside the next levels
+    hipEvent_t ev_level[RT_MAX_LEVELS] = {};  // level l intersected and spawned
+    hipEvent_t ev_shadow = nullptr;           // all shadow launches done
     bool kernels_ready = false;
 };
 
@@ -79,6 +83,9 @@ struct rt_scene {
 };
 
 namespace {
+
+constexpr uint32_t LV_SHADOW_BASE = 2 * RT_MAX_LEVELS, LV_SHADOW_TOTAL = 3 * RT_MAX_LEVELS + 1,
+                   LV_OVERFLOW = 3 * RT_MAX_LEVELS + 2, LV_WORDS = 3 * RT_MAX_LEVELS + 3;
 
 int fail(rt_context* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -142,7 +149,10 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, RT_ERR_UNSUPPORTED, std::string("librtamd is built for gfx950 only; device is ") + prop.gcnArchName);
     for (auto& e : ctx->ev) RT_HIP(ctx, hipEventCreate(&e));
-    RT_HIP(ctx, ctx->levels.alloc(3 * RT_MAX_LEVELS + 1));
+    RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->shadow_stream, hipStreamNonBlocking));
+    for (auto& e : ctx->ev_level) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_shadow, hipEventDisableTiming));
+    RT_HIP(ctx, ctx->levels.alloc(LV_WORDS));
     RT_HIP(ctx, ctx->counters.alloc(20));
     return RT_OK;
 }
@@ -151,6 +161,10 @@ extern "C" void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_level)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_shadow) (void)hipEventDestroy(ctx->ev_shadow);
+    if (ctx->shadow_stream) (void)hipStreamDestroy(ctx->shadow_stream);
     delete ctx;
 }
 
@@ -223,8 +237,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
                 poly_items.push_back(make_uint4(prim, k, sd.polygons[p.index].first_vertex, sd.polygons[p.index].vertex_count));
             }
         }
+        const uint32_t u0 = cluster_spheres(ls, bnd);  // re-ordered, padded to 8, bounding records appended
         const uint32_t ns = (uint32_t)ls.size();
-        const uint32_t u0 = cluster_spheres(ls, bnd);  // spatial order, padded to 8, bounding records appended
         for (const LeafSphere& e : ls) {
             sph.push_back(make_float4(e.c[0], e.c[1], e.c[2], e.r * e.r));  // src/sphere.rs:53
             sph_id.push_back(make_uint2(e.prim, e.pos));
@@ -376,10 +390,11 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
     const bool cull = opt->exhaustive_leaves == 0;
     const uint32_t n_lights = scene->dev.n_lights;
     size_t cap = std::max<size_t>(ctx->pool_cap, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
-    size_t scap = std::max<size_t>(ctx->shadow_cap, std::max<size_t>((size_t)n_slots * n_lights, 1u << 16));
+    // one shadow queue for the whole frame: the primary hits' rays and about as many again
+    size_t scap = std::max<size_t>(ctx->shadow_cap, std::max<size_t>((size_t)n_slots * n_lights * 2, 1u << 16));
     rt_stats stats;
     memset(&stats, 0, sizeof(stats));
-    uint32_t lv[3 * RT_MAX_LEVELS + 1];
+    uint32_t lv[LV_WORDS];
 
     for (uint32_t attempt = 0;; ++attempt) {
         if (cap > 0xfffffff0ull || scap > 0xfffffff0ull)
@@ -402,11 +417,12 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         A.shadow_cap = (uint32_t)ctx->shadow_cap;
         A.level_count = ctx->levels.p;
         A.level_base = ctx->levels.p + RT_MAX_LEVELS;
-        A.shadow_count = ctx->levels.p + 2 * RT_MAX_LEVELS;
-        A.overflow = ctx->levels.p + 3 * RT_MAX_LEVELS;
+        A.shadow_base = ctx->levels.p + LV_SHADOW_BASE;
+        A.shadow_total = ctx->levels.p + LV_SHADOW_TOTAL;
+        A.overflow = ctx->levels.p + LV_OVERFLOW;
         A.counters = ctx->counters.p;
 
-        RT_HIP(ctx, hipMemsetAsync(ctx->levels.p, 0, (3 * RT_MAX_LEVELS + 1) * sizeof(uint32_t), st));
+        RT_HIP(ctx, hipMemsetAsync(ctx->levels.p, 0, LV_WORDS * sizeof(uint32_t), st));
         RT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 20 * sizeof(unsigned long long), st));
         RT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
 
@@ -416,12 +432,23 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         const uint32_t gridn = std::min<uint32_t>(grid0, 16384);
         const uint32_t grids = (uint32_t)std::min<uint64_t>(
             std::max<uint64_t>(1, ((uint64_t)n_slots * n_lights + RT_BLOCK - 1) / RT_BLOCK), 65536);
+        hipStream_t st2 = ctx->shadow_stream;
         for (uint32_t level = 0; level <= opt->max_depth; ++level) {
             const uint32_t g = level == 0 ? grid0 : gridn;
             RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
-            if (n_lights)
-                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, cull, grids, st) : rt_exact::launch_shadow(A, level, work, cull, grids, st));
-            RT_HIP(ctx, fast ? rt_fast::launch_shade(A, level, work, g, st) : rt_exact::launch_shade(A, level, work, g, st));
+            RT_HIP(ctx, fast ? rt_fast::launch_spawn(A, level, g, st) : rt_exact::launch_spawn(A, level, g, st));
+            if (n_lights) {  // this level's shadow rays: beside the next levels, on the second stream
+                RT_HIP(ctx, hipEventRecord(ctx->ev_level[level], st));
+                RT_HIP(ctx, hipStreamWaitEvent(st2, ctx->ev_level[level], 0));
+                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn * 2, st2)
+                                 : rt_exact::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn * 2, st2));
+            }
+        }
+        if (n_lights) {
+            RT_HIP(ctx, hipEventRecord(ctx->ev_shadow, st2));
+            RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_shadow, 0));
+            RT_HIP(ctx, fast ? rt_fast::launch_light(A, opt->max_depth, work, grid0 * 2, st)
+                             : rt_exact::launch_light(A, opt->max_depth, work, grid0 * 2, st));
         }
         RT_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         for (uint32_t level = opt->max_depth + 1; level-- > 0;) {
@@ -432,10 +459,10 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         RT_HIP(ctx, hipStreamSynchronize(st));
 
         RT_HIP(ctx, hipMemcpy(lv, ctx->levels.p, sizeof(lv), hipMemcpyDeviceToHost));
-        if (lv[3 * RT_MAX_LEVELS] != 0) {  // a pool overflowed: grow and run the frame again
-            uint64_t need = n_slots, sneed = 0;
+        if (lv[LV_OVERFLOW] != 0) {  // a pool overflowed: grow and run the frame again
+            uint64_t need = n_slots;
+            const uint64_t sneed = lv[LV_SHADOW_TOTAL];
             for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
-            for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed = std::max<uint64_t>(sneed, lv[2 * RT_MAX_LEVELS + l]);
             if (need > ctx->pool_cap) cap = std::max<size_t>(ctx->pool_cap * 2, (size_t)need + (need >> 2));
             if (sneed > ctx->shadow_cap) scap = std::max<size_t>(ctx->shadow_cap * 2, (size_t)sneed + (sneed >> 2));
             if (need <= ctx->pool_cap && sneed <= ctx->shadow_cap) { cap = ctx->pool_cap * 2; scap = ctx->shadow_cap * 2; }
@@ -446,8 +473,7 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         unsigned long long c[20];
         RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         stats.rays_primary = n_primary;
-        stats.rays_shadow = 0;
-        for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += lv[2 * RT_MAX_LEVELS + l];
+        stats.rays_shadow = lv[LV_SHADOW_TOTAL];
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
         for (int k = 0; k < 16; ++k) stats.work[k] = c[4 + k];

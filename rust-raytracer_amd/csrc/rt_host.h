@@ -24,8 +24,9 @@ struct LeafSphere {
     float r;
     uint32_t prim, pos;  // primitive id, position in the leaf's list
 };
-// Re-orders `v` spatially, pads it to a multiple of 8 entries, and appends the leaf's block of
-// bounding records to `bnd` (4 floats each); returns the index of the block's header record.
+// Re-orders `v` by size and position, pads it to a multiple of 8 entries (padding = copies of
+// entries with bit 31 of `pos` set), and appends the leaf's block of bounding records to `bnd`
+// (4 floats each); returns the index of the block's header record.
 uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd);
 
 // Validates counts, pointers and every index in a scene description.

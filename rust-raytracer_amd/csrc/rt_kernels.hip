@@ -3,19 +3,22 @@
 //
 // Frame structure (replaces the recursion of Scene::sub_trace, reference src/scene.rs:82-200):
 // the ray tree is evaluated level by level.  Level 0 holds one ray per pixel slot.  Every
-// ray owns one node in a pool (node index = ray index).  Per level three kernels run:
+// ray owns one node in a pool (node index = ray index).  Per level, on the frame's stream:
 //   k_intersect  closest hit of every ray of the level (src/scene.rs:90); for each front-face
-//                hit it appends one shadow ray per light (src/scene.rs:103-112) to the shadow
-//                queue with a wave-wide ballot + prefix count and one atomic per wave;
-//   k_shadow     closest hit of every shadow ray -> blocked flag (src/scene.rs:108-117);
-//   k_shade      direct lighting from the unblocked lights in light order (src/scene.rs:119-124),
-//                then appends the reflection / refraction rays the hit spawns
-//                (src/scene.rs:127-193) to level d+1, again by ballot + prefix count.
-// The node keeps the direct colour, the two child indices and their weights.  After the
-// last level, resolve kernels run from the deepest level up: total = direct + refl *
-// reflectance + refr * transmittance in that order, clamped per node exactly as
-// src/scene.rs:195 does before the parent multiplies it -- the clamp makes the recursion
-// non-linear, so path-throughput accumulation would not reproduce it.
+//                hit it appends one shadow ray per light (src/scene.rs:103-112) to the frame's
+//                shadow queue with a wave-wide ballot + prefix count and one atomic per wave;
+//   k_spawn      appends the reflection / refraction rays the hits spawn (src/scene.rs:127-193)
+//                to level d+1, again by ballot + prefix count.
+// The shadow rays of a level do not feed the next level, so they are traced on a second
+// stream while the next levels' (ever smaller) launches run:
+//   k_shadow     closest hit of every shadow ray of one level -> blocked flag (src/scene.rs:108-117).
+// When both streams are done:
+//   k_light      direct lighting of every node from its unblocked lights, in light order
+//                (src/scene.rs:119-124);
+//   k_resolve    from the deepest level up: total = direct + refl * reflectance + refr *
+//                transmittance in that order, clamped per node exactly as src/scene.rs:195 does
+//                before the parent multiplies it -- the clamp makes the recursion non-linear, so
+//                path-throughput accumulation would not reproduce it.
 #include <hip/hip_runtime.h>
 
 #include "rt_traverse.h"
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t le
         const uint32_t c_lit = (uint32_t)__popcll(m_lit);
         if (c_lit) {
             uint32_t slot0 = 0;
-            if (lane_id() == 0) slot0 = atomicAdd(&A.shadow_count[level], c_lit * n_lights);
+            if (lane_id() == 0) slot0 = atomicAdd(A.shadow_total, c_lit * n_lights);
             slot0 = __builtin_amdgcn_readfirstlane(slot0);
             if (lit) {
                 const uint32_t first = slot0 + prefix_count(m_lit);
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t le
                 }
             }
         }
-        if (active && !lit) A.node_sh[node] = make_uint2(NONE, 0u);
+        if (i < count && !lit) A.node_sh[node] = make_uint2(NONE, 0u);  // also the padding slots of edge tiles
     }
     flush_work(A, ctr);
 }
@@ -191,10 +194,9 @@ template <bool CULL, class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK) k_shadow(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
-    const uint32_t wanted = A.shadow_count[level];
-    const uint32_t count = wanted < A.shadow_cap ? wanted : A.shadow_cap;
+    const uint32_t first = A.shadow_base[level], end = A.shadow_base[level + 1];  // clamped to the queue's size
     Ctr ctr;
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
+    for (uint32_t i = first + blockIdx.x * RT_BLOCK + threadIdx.x; i < end; i += gridDim.x * RT_BLOCK) {
         const float4 so = A.sray_o[i];
         const float4 sd = A.sray_d[i];
         Hit blocker;
@@ -208,15 +210,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(FrameArgs A, uint32_t level
 }
 
 // ---------------------------------------------------------------------------------------
-// k_shade: direct lighting + spawning the next level
+// k_spawn: the next level's rays.  Leaves in the node: {background or 0, reflectance weight}
+// and the child links; k_light adds the direct light later.
 // ---------------------------------------------------------------------------------------
-template <bool LEVEL0, class Ctr>
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(FrameArgs A, uint32_t level) {
+template <bool LEVEL0>
+__global__ void __launch_bounds__(RT_BLOCK) k_spawn(FrameArgs A, uint32_t level) {
     const DevScene& S = A.scene;
     const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
     const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
     const uint32_t next_base = base + count;
-    Ctr ctr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // k_intersect of this level is complete: its shadow rays end here
+        const uint32_t t = *A.shadow_total;
+        A.shadow_base[level + 1] = t < A.shadow_cap ? t : A.shadow_cap;
+    }
     uint32_t n_refl = 0, n_refr = 0;
 
     for (uint32_t chunk = blockIdx.x * RT_BLOCK; chunk < count; chunk += gridDim.x * RT_BLOCK) {
@@ -236,26 +242,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(FrameArgs A, uint32_t level)
             hit_prim = A.hit_p[node];
             if (hit_prim != NO_PRIM) {
                 is_hit = true;
-                const float4 ha = A.hit_a[node];
-                const F3 normal = f3(ha.x, ha.y, ha.z);
-                const Surface surf = load_surface(S, S.prim_surface[hit_prim]);
-                pos = add(ray.src, mul(ray.dir, ha.w));               // src/scene.rs:95
-                const bool back_face = dot(normal, ray.dir) > 0.0f;   // :96
-                if (!back_face) {
-                    const uint2 sh = A.node_sh[node];
-                    for (uint32_t l = 0; l < S.n_lights && sh.x != NONE; ++l) {  // :103-125, in light order
-                        const uint32_t s = sh.x + l * sh.y;
-                        if (A.sray_blocked[s] == 0u) {
-                            ctr.shade_evals(1);
-                            const float4 sd = A.sray_d[s];
-                            const float4 lc = S.lights[l * 2 + 1];
-                            const F3 ldir = f3(sd.x, sd.y, sd.z), lcol = f3(lc.x, lc.y, lc.z);
-                            const F3 direct = surf.model == 0u ? shade_phong(surf, normal, ray.dir, ldir, lcol)
-                                                               : shade_blinn_phong(surf, normal, ray.dir, ldir, lcol);
-                            total = add(total, direct);
-                        }
-                    }
-                    if (level < A.max_depth) {  // :127-144
+                if (level < A.max_depth) {
+                    const float4 ha = A.hit_a[node];
+                    const F3 normal = f3(ha.x, ha.y, ha.z);
+                    const Surface surf = load_surface(S, S.prim_surface[hit_prim]);
+                    pos = add(ray.src, mul(ray.dir, ha.w));               // src/scene.rs:95
+                    const bool back_face = dot(normal, ray.dir) > 0.0f;   // :96
+                    if (!back_face) {  // :127-144
                         refl_contrib = ray.contribution * surf.reflectance;
                         if (refl_contrib > A.min_contribution) {
                             want_refl = true;
@@ -263,8 +256,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(FrameArgs A, uint32_t level)
                             reflectance = surf.reflectance;
                         }
                     }
-                }
-                if (level < A.max_depth) {  // :147-193
+                    // :147-193
                     if (back_face) transmittance = surf.transmittance > A.min_contribution ? 1.0f : 0.0f;
                     else transmittance = surf.transmittance;
                     refr_contrib = ray.contribution * transmittance;
@@ -306,11 +298,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(FrameArgs A, uint32_t level)
             A.ray_d[refr_idx] = make_float4(refr_ray.x, refr_ray.y, refr_ray.z, __uint_as_float(NO_PRIM));
         }
         if (active) {
-            if (is_hit && !want_refl && !want_refr) {  // no children: final already (:195)
-                total.x = total.x > 1.0f ? 1.0f : total.x;
-                total.y = total.y > 1.0f ? 1.0f : total.y;
-                total.z = total.z > 1.0f ? 1.0f : total.z;
-            }
             A.node_col[node] = make_float4(total.x, total.y, total.z, reflectance);
             A.node_kid[node] = make_uint4(refl_idx, refr_idx, __float_as_uint(transmittance), is_hit ? 1u : 0u);
         }
@@ -320,6 +307,50 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(FrameArgs A, uint32_t level)
     if (lane_id() == 0) {
         if (s_refl) atomicAdd(&A.counters[2], (unsigned long long)s_refl);
         if (s_refr) atomicAdd(&A.counters[3], (unsigned long long)s_refr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_light: direct lighting of every node of the frame (all levels in one launch), once the
+// shadow rays are traced.
+// ---------------------------------------------------------------------------------------
+template <class Ctr>
+__global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t last_level) {
+    const DevScene& S = A.scene;
+    const uint32_t n_nodes = A.level_base[last_level + 1];  // end of the deepest level
+    Ctr ctr;
+    for (uint32_t node = blockIdx.x * RT_BLOCK + threadIdx.x; node < n_nodes; node += gridDim.x * RT_BLOCK) {
+        const uint2 sh = A.node_sh[node];
+        if (sh.x == NONE) continue;  // miss, back face, padding slot, or no lights
+        const uint32_t hit_prim = A.hit_p[node];
+        Ray ray;
+        if (node < A.n_slots) fetch_ray<true>(A, node, node, ray);
+        else fetch_ray<false>(A, node, node, ray);
+        const float4 ha = A.hit_a[node];
+        const F3 normal = f3(ha.x, ha.y, ha.z);
+        const Surface surf = load_surface(S, S.prim_surface[hit_prim]);
+        F3 total = f3(0.0f, 0.0f, 0.0f);
+        for (uint32_t l = 0; l < S.n_lights; ++l) {  // src/scene.rs:103-125, in light order
+            const uint32_t s = sh.x + l * sh.y;
+            if (A.sray_blocked[s] == 0u) {
+                ctr.shade_evals(1);
+                const float4 sd = A.sray_d[s];
+                const float4 lc = S.lights[l * 2 + 1];
+                const F3 ldir = f3(sd.x, sd.y, sd.z), lcol = f3(lc.x, lc.y, lc.z);
+                const F3 direct = surf.model == 0u ? shade_phong(surf, normal, ray.dir, ldir, lcol)
+                                                   : shade_blinn_phong(surf, normal, ray.dir, ldir, lcol);
+                total = add(total, direct);
+            }
+        }
+        const uint4 kid = A.node_kid[node];
+        if (kid.x == NONE && kid.y == NONE) {  // no children: final already (src/scene.rs:195)
+            total.x = total.x > 1.0f ? 1.0f : total.x;
+            total.y = total.y > 1.0f ? 1.0f : total.y;
+            total.z = total.z > 1.0f ? 1.0f : total.z;
+        }
+        float4 col = A.node_col[node];
+        col.x = total.x; col.y = total.y; col.z = total.z;
+        A.node_col[node] = col;
     }
     flush_work(A, ctr);
 }
@@ -536,14 +567,15 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, bool cul
     return hipGetLastError();
 }
 
-hipError_t launch_shade(const FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st) {
-    if (level == 0) {
-        if (work) hipLaunchKernelGGL((k_shade<true, WorkCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
-        else hipLaunchKernelGGL((k_shade<true, NoCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
-    } else {
-        if (work) hipLaunchKernelGGL((k_shade<false, WorkCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
-        else hipLaunchKernelGGL((k_shade<false, NoCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
-    }
+hipError_t launch_spawn(const FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st) {
+    if (level == 0) hipLaunchKernelGGL((k_spawn<true>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+    else hipLaunchKernelGGL((k_spawn<false>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+    return hipGetLastError();
+}
+
+hipError_t launch_light(const FrameArgs& A, uint32_t last_level, bool work, uint32_t grid, hipStream_t st) {
+    if (work) hipLaunchKernelGGL((k_light<WorkCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, last_level);
+    else hipLaunchKernelGGL((k_light<NoCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, last_level);
     return hipGetLastError();
 }
 

@@ -55,12 +55,13 @@ struct FrameArgs {
     uint32_t pool_cap;
     uint32_t* level_count;  // [RT_MAX_LEVELS]
     uint32_t* level_base;   // [RT_MAX_LEVELS]
-    // shadow-ray queue of the level in flight (reused by every level)
+    // shadow-ray queue of the frame
     float4* sray_o;         // origin.xyz, distance to the light
     float4* sray_d;         // direction.xyz, bits(ignored primitive)
     uint32_t* sray_blocked; // 1 = a primitive lies between the surface and the light
     uint32_t shadow_cap;
-    uint32_t* shadow_count; // [RT_MAX_LEVELS]
+    uint32_t* shadow_total; // shadow rays wanted so far in this frame (one queue for all levels)
+    uint32_t* shadow_base;  // [RT_MAX_LEVELS + 1] first queue slot of each level's shadow rays
     uint32_t* overflow;
     unsigned long long* counters;  // [17]: primary, shadow, reflect, refract, then the 13 work counters
     // outputs (either may be null)
@@ -82,7 +83,8 @@ struct DeinterleaveArgs {
     hipError_t init_kernels();                                                                                       \
     hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st); \
     hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st); \
-    hipError_t launch_shade(const rtamd::FrameArgs& A, uint32_t level, bool work, uint32_t grid, hipStream_t st);    \
+    hipError_t launch_spawn(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);               \
+    hipError_t launch_light(const rtamd::FrameArgs& A, uint32_t last_level, bool work, uint32_t grid, hipStream_t st); \
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
     hipError_t launch_debug_intersect(const rtamd::DevScene& S, bool cull, uint64_t n, const float* src, const float* ray, \

@@ -101,7 +101,9 @@ RT_DEV void sphere_finish(const DevScene& S, uint32_t entry, float d, float c, f
         if (t >= near) {
             const uint2 id = ld_u2<U>(S.sph_id, entry);
             if (id.x != ignore) {  // src/space_partition.rs:361-366
-                ctr.sphere_hits(1);
+                if constexpr (Ctr::kEnabled) {
+                    if ((id.y >> 31) == 0u) ctr.sphere_hits(1);  // padding copies are not the reference's work
+                }
                 if (lb.better(t, id.y)) {
                     lb.have = true; lb.t = t; lb.pos = id.y; lb.prim = id.x; lb.sphere = entry;
                 }
@@ -140,8 +142,10 @@ RT_DEV void leaf_spheres(const DevScene& S, uint32_t first, uint32_t count, F3 s
             const bool m2 = sphere_quick(cur[8], cur[9], cur[10], cur[11], src, ray, a, d2, c2);
             const bool m3 = sphere_quick(cur[12], cur[13], cur[14], cur[15], src, ray, a, d3, c3);
             if constexpr (Ctr::kEnabled) {  // the reference skips the ignored primitive before testing it
-                for (uint32_t j = 0; j < 4 && k + j < count; ++j)
-                    if (ld_u2<true>(S.sph_id, first + k + j).x != ignore) ctr.sphere_tests(1);
+                for (uint32_t j = 0; j < 4 && k + j < count; ++j) {
+                    const uint2 id = ld_u2<true>(S.sph_id, first + k + j);
+                    if (id.x != ignore && (id.y >> 31) == 0u) ctr.sphere_tests(1);  // not the padding copies
+                }
             }
             // one scalar branch per step: does any lane of the wave pass any of the four?
             if ((__ballot(m0) | __ballot(m1) | __ballot(m2) | __ballot(m3)) != 0ull) {
@@ -157,7 +161,8 @@ RT_DEV void leaf_spheres(const DevScene& S, uint32_t first, uint32_t count, F3 s
             const float4 s = S.sph[first + k];
             float d, c;
             if constexpr (Ctr::kEnabled) {
-                if (S.sph_id[first + k].x != ignore) ctr.sphere_tests(1);
+                const uint2 id = S.sph_id[first + k];
+                if (id.x != ignore && (id.y >> 31) == 0u) ctr.sphere_tests(1);  // not the padding copies
             }
             if (sphere_quick(s.x, s.y, s.z, s.w, src, ray, a, d, c))
                 sphere_finish<false>(S, first + k, d, c, a, near, ignore, lb, ctr);
@@ -250,8 +255,8 @@ RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 ray, floa
     return valid >= 8u ? m : (m & ((1u << valid) - 1u));
 }
 
-// The 8 spheres of entries e0 .. e0+7 (padding entries are copies of the run's last sphere:
-// same distance, same list position, so accepting one again changes nothing).
+// The 8 spheres of entries e0 .. e0+7.  Padding entries are copies of real entries with a
+// later list position: whatever a copy hits, its original hits at the same distance and wins.
 template <class Ctr>
 RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, float near, uint32_t ignore, LeafBest& lb,
                      Ctr& ctr) {
