@@ -134,7 +134,8 @@ void arrange(std::vector<LeafSphere>& v) {
 
 // Block layout in `bnd` (4 floats per record, indices in records):
 //   [h]            header, as integers: {first level-2 record, first level-3, first level-4, top level}
-//   [h+1 ...]      level-1 records (one per 8 entries), then levels 2, 3, 4.
+//   [h+1]          one record bounding the whole run
+//   [h+2 ...]      level-1 records (one per 8 entries), then levels 2, 3, 4.
 // Record i of level L bounds records 8i .. 8i+7 of level L-1 (entries 8i .. 8i+7 for L = 1).
 // The top level is the lowest one with at most 16 records (level 4 if none is that small); the
 // device tests it linearly and descends from there.
@@ -144,7 +145,12 @@ uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd) {
     arrange(v);
     const size_t n = v.size();  // a multiple of 8
     bnd.insert(bnd.end(), 4, 0.0f);
-    uint32_t first[5] = {0, h + 1, 0, 0, 0};
+    {
+        float rec[4];
+        bound(v, 0, n, rec);
+        bnd.insert(bnd.end(), rec, rec + 4);
+    }
+    uint32_t first[5] = {0, h + 2, 0, 0, 0};
     size_t count[5] = {0, 0, 0, 0, 0};
     size_t span = 8;  // entries per record of the level
     for (int L = 1; L <= 4; ++L, span *= 8) {

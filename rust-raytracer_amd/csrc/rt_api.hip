@@ -389,19 +389,22 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
     const bool work = opt->collect_work != 0;
     const bool cull = opt->exhaustive_leaves == 0;
     const uint32_t n_lights = scene->dev.n_lights;
+    if (n_lights > 65535) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 65535 lights");
     size_t cap = std::max<size_t>(ctx->pool_cap, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
-    // one shadow queue for the whole frame: the primary hits' rays and about as many again
-    size_t scap = std::max<size_t>(ctx->shadow_cap, std::max<size_t>((size_t)n_slots * n_lights * 2, 1u << 16));
+    // shadow queues hold the whole frame: room for the primary hits and about as many again,
+    // times the number of lights
+    const size_t lights1 = std::max<uint32_t>(1, n_lights);
+    size_t scap = std::max<size_t>(ctx->shadow_cap / lights1, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
     rt_stats stats;
     memset(&stats, 0, sizeof(stats));
     uint32_t lv[LV_WORDS];
 
     for (uint32_t attempt = 0;; ++attempt) {
-        if (cap > 0xfffffff0ull || scap > 0xfffffff0ull)
+        if (cap > 0xfffffff0ull || scap * lights1 > 0xfffffff0ull)
             return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
         rc = ensure_pool(ctx, cap);
         if (rc != RT_OK) return rc;
-        rc = ensure_shadow(ctx, scap);
+        rc = ensure_shadow(ctx, scap * lights1);
         if (rc != RT_OK) return rc;
         A.ray_o = ctx->ray_o.p;
         A.ray_d = ctx->ray_d.p;
@@ -414,7 +417,7 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         A.sray_o = ctx->sray_o.p;
         A.sray_d = ctx->sray_d.p;
         A.sray_blocked = ctx->sray_blocked.p;
-        A.shadow_cap = (uint32_t)ctx->shadow_cap;
+        A.shadow_cap = (uint32_t)(ctx->shadow_cap / lights1);
         A.level_count = ctx->levels.p;
         A.level_base = ctx->levels.p + RT_MAX_LEVELS;
         A.shadow_base = ctx->levels.p + LV_SHADOW_BASE;
@@ -430,8 +433,7 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         // Deeper levels' sizes are only known on the device; launch enough blocks for the
         // largest plausible level and let blocks past the end exit (grid-stride inside).
         const uint32_t gridn = std::min<uint32_t>(grid0, 16384);
-        const uint32_t grids = (uint32_t)std::min<uint64_t>(
-            std::max<uint64_t>(1, ((uint64_t)n_slots * n_lights + RT_BLOCK - 1) / RT_BLOCK), 65536);
+        const uint32_t grids = std::min<uint32_t>(grid0, 65535);  // per light: the launch is (grids, n_lights)
         hipStream_t st2 = ctx->shadow_stream;
         for (uint32_t level = 0; level <= opt->max_depth; ++level) {
             const uint32_t g = level == 0 ? grid0 : gridn;
@@ -440,8 +442,8 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
             if (n_lights) {  // this level's shadow rays: beside the next levels, on the second stream
                 RT_HIP(ctx, hipEventRecord(ctx->ev_level[level], st));
                 RT_HIP(ctx, hipStreamWaitEvent(st2, ctx->ev_level[level], 0));
-                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn * 2, st2)
-                                 : rt_exact::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn * 2, st2));
+                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn, st2)
+                                 : rt_exact::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn, st2));
             }
         }
         if (n_lights) {
@@ -464,8 +466,8 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
             const uint64_t sneed = lv[LV_SHADOW_TOTAL];
             for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
             if (need > ctx->pool_cap) cap = std::max<size_t>(ctx->pool_cap * 2, (size_t)need + (need >> 2));
-            if (sneed > ctx->shadow_cap) scap = std::max<size_t>(ctx->shadow_cap * 2, (size_t)sneed + (sneed >> 2));
-            if (need <= ctx->pool_cap && sneed <= ctx->shadow_cap) { cap = ctx->pool_cap * 2; scap = ctx->shadow_cap * 2; }
+            if (sneed > A.shadow_cap) scap = std::max<size_t>((size_t)A.shadow_cap * 2, (size_t)sneed + (sneed >> 2));
+            if (need <= ctx->pool_cap && sneed <= A.shadow_cap) { cap = ctx->pool_cap * 2; scap = (size_t)A.shadow_cap * 2; }
             stats.retries = attempt + 1;
             if (attempt >= 8) return fail(ctx, RT_ERR_CAPACITY, "ray pool still too small after 8 growth steps");
             continue;
@@ -473,7 +475,7 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         unsigned long long c[20];
         RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         stats.rays_primary = n_primary;
-        stats.rays_shadow = lv[LV_SHADOW_TOTAL];
+        stats.rays_shadow = (uint64_t)lv[LV_SHADOW_TOTAL] * n_lights;
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
         for (int k = 0; k < 16; ++k) stats.work[k] = c[4 + k];

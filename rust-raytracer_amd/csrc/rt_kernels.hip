@@ -124,7 +124,7 @@ RT_DEV bool fetch_ray(const FrameArgs& A, uint32_t i, uint32_t node, Ray& r) {
 // k_intersect: closest hit of every ray of one level + its shadow rays
 // ---------------------------------------------------------------------------------------
 template <bool LEVEL0, bool CULL, class Ctr>
-__global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t level) {
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
     const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
@@ -153,18 +153,21 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t le
                 lit = !(dot(hit.n, ray.dir) > 0.0f) && n_lights > 0;  // src/scene.rs:96, :102
             }
         }
-        // ---- one shadow ray per light for every front-face hit; a wave's rays of one light are adjacent
+        // ---- one shadow ray per light for every front-face hit.  Each light has its own queue
+        // (a slice of the arrays, shadow_cap slots long) and a hit uses the same slot in all of
+        // them, so that 64 consecutive slots of a queue are rays towards one light from
+        // neighbouring hits.
         const uint64_t m_lit = __ballot(lit);
         const uint32_t c_lit = (uint32_t)__popcll(m_lit);
         if (c_lit) {
             uint32_t slot0 = 0;
-            if (lane_id() == 0) slot0 = atomicAdd(A.shadow_total, c_lit * n_lights);
+            if (lane_id() == 0) slot0 = atomicAdd(A.shadow_total, c_lit);
             slot0 = __builtin_amdgcn_readfirstlane(slot0);
             if (lit) {
                 const uint32_t first = slot0 + prefix_count(m_lit);
-                const bool fits = slot0 + c_lit * n_lights <= A.shadow_cap;
+                const bool fits = slot0 + c_lit <= A.shadow_cap;
                 if (!fits) *A.overflow = 1u;
-                A.node_sh[node] = make_uint2(fits ? first : NONE, c_lit);
+                A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
                 if (fits) {
                     const F3 pos = add(ray.src, mul(ray.dir, hit.dist));  // src/scene.rs:95
                     for (uint32_t l = 0; l < n_lights; ++l) {             // src/scene.rs:103-112
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t le
                         const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
                         const float ldist = magnitude(to_light);
                         const F3 ldir = divs(to_light, ldist);
-                        const uint32_t s = first + l * c_lit;
+                        const uint64_t s = (uint64_t)l * A.shadow_cap + first;
                         A.sray_o[s] = make_float4(pos.x, pos.y, pos.z, ldist);
                         A.sray_d[s] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(hit.prim));
                     }
@@ -191,12 +194,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_intersect(FrameArgs A, uint32_t le
 // <= the light's distance.
 // ---------------------------------------------------------------------------------------
 template <bool CULL, class Ctr>
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(FrameArgs A, uint32_t level) {
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
     const uint32_t first = A.shadow_base[level], end = A.shadow_base[level + 1];  // clamped to the queue's size
+    const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;                   // blockIdx.y = light
     Ctr ctr;
-    for (uint32_t i = first + blockIdx.x * RT_BLOCK + threadIdx.x; i < end; i += gridDim.x * RT_BLOCK) {
+    for (uint32_t k = first + blockIdx.x * RT_BLOCK + threadIdx.x; k < end; k += gridDim.x * RT_BLOCK) {
+        const uint64_t i = queue + k;
         const float4 so = A.sray_o[i];
         const float4 sd = A.sray_d[i];
         Hit blocker;
@@ -331,7 +336,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t last_l
         const Surface surf = load_surface(S, S.prim_surface[hit_prim]);
         F3 total = f3(0.0f, 0.0f, 0.0f);
         for (uint32_t l = 0; l < S.n_lights; ++l) {  // src/scene.rs:103-125, in light order
-            const uint32_t s = sh.x + l * sh.y;
+            const uint64_t s = (uint64_t)l * sh.y + sh.x;
             if (A.sray_blocked[s] == 0u) {
                 ctr.shade_evals(1);
                 const float4 sd = A.sray_d[s];
@@ -559,7 +564,7 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 
 hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
-    const dim3 g(grid), b(RT_BLOCK);
+    const dim3 g(grid, A.scene.n_lights), b(RT_BLOCK);
     if (work && cull) hipLaunchKernelGGL((k_shadow<true, WorkCounters>), g, b, lds, st, A, level);
     else if (work) hipLaunchKernelGGL((k_shadow<false, WorkCounters>), g, b, lds, st, A, level);
     else if (cull) hipLaunchKernelGGL((k_shadow<true, NoCounters>), g, b, lds, st, A, level);

@@ -49,7 +49,7 @@ struct FrameArgs {
     float4* ray_d;     // direction.xyz, bits(ignore primitive)
     float4* hit_a;     // closest hit: normal.xyz, distance
     uint32_t* hit_p;   // closest hit: primitive, 0xffffffff = miss
-    uint2* node_sh;    // shadow rays of this node's hit: {slot of light 0, slot stride between lights}
+    uint2* node_sh;    // shadow rays of this node's hit: {slot in every light's queue, slots per queue}
     float4* node_col;  // direct (later total) colour, reflectance weight
     uint4* node_kid;   // reflection child, refraction child, bits(transmittance weight), hit flag
     uint32_t pool_cap;
@@ -59,9 +59,9 @@ struct FrameArgs {
     float4* sray_o;         // origin.xyz, distance to the light
     float4* sray_d;         // direction.xyz, bits(ignored primitive)
     uint32_t* sray_blocked; // 1 = a primitive lies between the surface and the light
-    uint32_t shadow_cap;
-    uint32_t* shadow_total; // shadow rays wanted so far in this frame (one queue for all levels)
-    uint32_t* shadow_base;  // [RT_MAX_LEVELS + 1] first queue slot of each level's shadow rays
+    uint32_t shadow_cap;    // slots per light's queue; light l owns [l * shadow_cap, (l + 1) * shadow_cap)
+    uint32_t* shadow_total; // lit hits so far in this frame (each takes one slot in every queue)
+    uint32_t* shadow_base;  // [RT_MAX_LEVELS + 1] first slot of each level's shadow rays
     uint32_t* overflow;
     unsigned long long* counters;  // [17]: primary, shadow, reflect, refract, then the 13 work counters
     // outputs (either may be null)

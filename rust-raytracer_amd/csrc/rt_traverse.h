@@ -221,13 +221,14 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
 //
 // The walk is split in two loops so that the lanes of a wave run the same code on different
 // data: first a depth-first descent whose only step is "test the 8 records of one group"
-// (pending sibling masks sit on a 3-entry per-lane stack in LDS), which queues {level-1 group,
+// (pending sibling masks sit on a 4-entry per-lane stack in LDS), which queues {level-1 group,
 // mask of live records}; then the queue is drained, each step testing the 8 spheres of one
 // live level-1 record with the reference's own arithmetic.
 // ---------------------------------------------------------------------------------------
 constexpr float CULL_ONE_MINUS_BETA = 0.999978f;  // 1 - 2.2e-5
 constexpr uint32_t CULL_MIN_SPHERES = 24;         // shorter runs are walked entry by entry
-constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - 3;  // per-lane LDS words: 3 stack entries + the queue
+constexpr uint32_t LANE_STACK = 4;                   // per-lane LDS words: 4 stack entries, then the queue
+constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - LANE_STACK;
 
 RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 ray, float a) {
     const float ex = src.x - rec.x, ey = src.y - rec.y, ez = src.z - rec.z;
@@ -292,7 +293,9 @@ template <class Ctr>
 RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, float a,
                               float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
     const float4 hf = S.bnd[header];
-    const uint32_t off1 = header + 1u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
+    ctr.bound_tests(1);
+    if (!bound_may_hit(S.bnd[header + 1u], src, ray, a)) return;  // misses the whole run
+    const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
                    off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w);
     const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
     auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : off4)); };
@@ -304,7 +307,7 @@ RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count,
         while (m != 0u || qn != 0u) {
             if (m == 0u) {
                 --qn;
-                const uint32_t e = lq[(3u + qn) * stride];
+                const uint32_t e = lq[(LANE_STACK + qn) * stride];
                 g = e >> 8;
                 m = e & 0xffu;
             }
@@ -314,15 +317,18 @@ RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count,
         }
     };
 
-    const uint32_t n_top = level_n(top);
-    for (uint32_t g0 = 0; g0 * 8u < n_top; ++g0) {
-        uint32_t L = top, g = g0, sp = 0;
-        uint32_t m = expand8(S.bnd + level_off(L) + g * 8u, n_top - g * 8u, src, ray, a, ctr);
+    // The groups of the top level are the children of a virtual record one level up, 8 groups
+    // (64 top records) per pass, so that one loop does the whole descent.
+    const uint32_t n_top_groups = (level_n(top) + 7u) >> 3;
+    for (uint32_t chunk = 0; chunk * 8u < n_top_groups; ++chunk) {
+        const uint32_t left = n_top_groups - chunk * 8u;
+        uint32_t L = top + 1u, g = chunk, sp = 0;
+        uint32_t m = left >= 8u ? 0xffu : ((1u << left) - 1u);
         for (;;) {
             if (L == 1u) {  // g is a level-1 group: queue its live records
                 if (m != 0u) {
                     ctr.bound_passes((uint32_t)__builtin_popcount(m));
-                    lq[(3u + qn) * stride] = (g << 8) | m;
+                    lq[(LANE_STACK + qn) * stride] = (g << 8) | m;
                     ++qn;
                     if (qn == LANE_QUEUE) drain();
                 }
@@ -332,14 +338,14 @@ RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count,
                 if (sp == 0u) break;
                 --sp;
                 const uint32_t e = lq[sp * stride];
-                L = e >> 30;
-                m = (e >> 22) & 0xffu;
-                g = e & 0x3fffffu;
+                L = e >> 29;
+                m = (e >> 21) & 0xffu;
+                g = e & 0x1fffffu;
             }
             const uint32_t k = (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
             if (m != 0u) {
-                lq[sp * stride] = (L << 30) | (m << 22) | g;
+                lq[sp * stride] = (L << 29) | (m << 21) | g;
                 ++sp;
             }
             g = g * 8u + k;  // record g*8+k of level L = group of that index one level down
