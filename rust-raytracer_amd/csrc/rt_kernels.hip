@@ -123,7 +123,7 @@ RT_DEV bool fetch_ray(const FrameArgs& A, uint32_t i, uint32_t node, Ray& r) {
 // ---------------------------------------------------------------------------------------
 // k_intersect: closest hit of every ray of one level + its shadow rays
 // ---------------------------------------------------------------------------------------
-template <bool LEVEL0, bool CULL, class Ctr>
+template <bool LEVEL0, int CULL, class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
 // a full closest-hit query ignoring the surface's own primitive, blocked iff its distance
 // <= the light's distance.
 // ---------------------------------------------------------------------------------------
-template <bool CULL, class Ctr>
+template <int CULL, class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_deinterleave(DeinterleaveArgs D) {
 // ---------------------------------------------------------------------------------------
 // diagnostics: device routines run one row per lane (parity tests)
 // ---------------------------------------------------------------------------------------
-template <bool CULL>
+template <int CULL>
 __global__ void __launch_bounds__(RT_BLOCK) k_debug_intersect(DevScene S, uint64_t n, const float* src, const float* ray,
                                                               const float* near, const uint32_t* ignore,
                                                               uint32_t* out_prim, float* out_dist, float* out_normal) {
@@ -529,14 +529,14 @@ static size_t stack_bytes(const DevScene& S) {
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
 hipError_t init_kernels() {
     const int max_lds = 160 * 1024;
-    const void* fns[] = {(const void*)k_intersect<true, true, WorkCounters>, (const void*)k_intersect<false, true, WorkCounters>,
-                         (const void*)k_shadow<true, WorkCounters>,
-                         (const void*)k_intersect<true, false, WorkCounters>, (const void*)k_intersect<true, false, NoCounters>,
-                         (const void*)k_intersect<true, true, NoCounters>, (const void*)k_intersect<false, false, WorkCounters>,
-                         (const void*)k_intersect<false, false, NoCounters>, (const void*)k_intersect<false, true, NoCounters>,
-                         (const void*)k_shadow<false, WorkCounters>, (const void*)k_shadow<false, NoCounters>,
-                         (const void*)k_shadow<true, NoCounters>, (const void*)k_debug_intersect<false>,
-                         (const void*)k_debug_intersect<true>};
+    const void* fns[] = {(const void*)k_intersect<true, 0, WorkCounters>, (const void*)k_intersect<true, 1, WorkCounters>,
+                         (const void*)k_intersect<true, 0, NoCounters>, (const void*)k_intersect<true, 1, NoCounters>,
+                         (const void*)k_intersect<false, 0, WorkCounters>, (const void*)k_intersect<false, 2, WorkCounters>,
+                         (const void*)k_intersect<false, 0, NoCounters>, (const void*)k_intersect<false, 2, NoCounters>,
+                         (const void*)k_shadow<0, WorkCounters>, (const void*)k_shadow<1, WorkCounters>,
+                         (const void*)k_shadow<2, WorkCounters>, (const void*)k_shadow<0, NoCounters>,
+                         (const void*)k_shadow<1, NoCounters>, (const void*)k_shadow<2, NoCounters>,
+                         (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         if (e != hipSuccess) return e;
@@ -548,16 +548,16 @@ hipError_t init_kernels() {
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
     const dim3 g(grid), b(RT_BLOCK);
-    if (level == 0) {
-        if (work && cull) hipLaunchKernelGGL((k_intersect<true, true, WorkCounters>), g, b, lds, st, A, level);
-        else if (work) hipLaunchKernelGGL((k_intersect<true, false, WorkCounters>), g, b, lds, st, A, level);
-        else if (cull) hipLaunchKernelGGL((k_intersect<true, true, NoCounters>), g, b, lds, st, A, level);
-        else hipLaunchKernelGGL((k_intersect<true, false, NoCounters>), g, b, lds, st, A, level);
+    if (level == 0) {  // camera rays start outside the scene: the line test alone
+        if (work && cull) hipLaunchKernelGGL((k_intersect<true, 1, WorkCounters>), g, b, lds, st, A, level);
+        else if (work) hipLaunchKernelGGL((k_intersect<true, 0, WorkCounters>), g, b, lds, st, A, level);
+        else if (cull) hipLaunchKernelGGL((k_intersect<true, 1, NoCounters>), g, b, lds, st, A, level);
+        else hipLaunchKernelGGL((k_intersect<true, 0, NoCounters>), g, b, lds, st, A, level);
     } else {
-        if (work && cull) hipLaunchKernelGGL((k_intersect<false, true, WorkCounters>), g, b, lds, st, A, level);
-        else if (work) hipLaunchKernelGGL((k_intersect<false, false, WorkCounters>), g, b, lds, st, A, level);
-        else if (cull) hipLaunchKernelGGL((k_intersect<false, true, NoCounters>), g, b, lds, st, A, level);
-        else hipLaunchKernelGGL((k_intersect<false, false, NoCounters>), g, b, lds, st, A, level);
+        if (work && cull) hipLaunchKernelGGL((k_intersect<false, 2, WorkCounters>), g, b, lds, st, A, level);
+        else if (work) hipLaunchKernelGGL((k_intersect<false, 0, WorkCounters>), g, b, lds, st, A, level);
+        else if (cull) hipLaunchKernelGGL((k_intersect<false, 2, NoCounters>), g, b, lds, st, A, level);
+        else hipLaunchKernelGGL((k_intersect<false, 0, NoCounters>), g, b, lds, st, A, level);
     }
     return hipGetLastError();
 }
@@ -565,10 +565,16 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
     const dim3 g(grid, A.scene.n_lights), b(RT_BLOCK);
-    if (work && cull) hipLaunchKernelGGL((k_shadow<true, WorkCounters>), g, b, lds, st, A, level);
-    else if (work) hipLaunchKernelGGL((k_shadow<false, WorkCounters>), g, b, lds, st, A, level);
-    else if (cull) hipLaunchKernelGGL((k_shadow<true, NoCounters>), g, b, lds, st, A, level);
-    else hipLaunchKernelGGL((k_shadow<false, NoCounters>), g, b, lds, st, A, level);
+    const int mode = !cull ? 0 : (level == 0 ? 1 : 2);  // deeper levels' hits lie among the spheres
+    if (work) {
+        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, level);
+        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, WorkCounters>), g, b, lds, st, A, level);
+        else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, level);
+    } else {
+        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, level);
+        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, NoCounters>), g, b, lds, st, A, level);
+        else hipLaunchKernelGGL((k_shadow<0, NoCounters>), g, b, lds, st, A, level);
+    }
     return hipGetLastError();
 }
 
@@ -600,8 +606,8 @@ hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, cons
                                   const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist,
                                   float* out_normal, hipStream_t st) {
     const dim3 g((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), b(RT_BLOCK);
-    if (cull) hipLaunchKernelGGL(k_debug_intersect<true>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
-    else hipLaunchKernelGGL(k_debug_intersect<false>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     return hipGetLastError();
 }
 

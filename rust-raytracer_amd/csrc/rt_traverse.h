@@ -226,28 +226,41 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
 // live level-1 record with the reference's own arithmetic.
 // ---------------------------------------------------------------------------------------
 constexpr float CULL_ONE_MINUS_BETA = 0.999978f;  // 1 - 2.2e-5
+constexpr float CULL_BETA = 2.2e-5f;
 constexpr uint32_t CULL_MIN_SPHERES = 24;         // shorter runs are walked entry by entry
 constexpr uint32_t LANE_STACK = 4;                   // per-lane LDS words: 4 stack entries, then the queue
 constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - LANE_STACK;
 
-RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 ray, float a) {
+// BEHIND adds the second way out, for rays that start among the spheres: the whole bounding
+// sphere lies behind the ray's origin,
+//     ray . E > 0  and  (ray . E)^2 > a * (q + beta |E|^2),
+// so every enclosed sphere could only be hit at t < 0 <= near.  `fwd` is false for a query
+// with near < 0, which must not use it.
+template <bool BEHIND>
+RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 ray, float a, bool fwd) {
     const float ex = src.x - rec.x, ey = src.y - rec.y, ez = src.z - rec.z;
     const float d = __builtin_fmaf(ray.z, ez, __builtin_fmaf(ray.y, ey, ray.x * ex));
     const float ee = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
     const float t = __builtin_fmaf(ee, CULL_ONE_MINUS_BETA, -rec.w);
-    return !(a * t > d * d);  // NaN anywhere keeps the group
+    const float dd = d * d;
+    bool keep = !(a * t > dd);  // NaN anywhere keeps the group
+    if constexpr (BEHIND) {
+        const float u = __builtin_fmaf(ee, CULL_BETA, rec.w);
+        keep = keep && !(fwd && d > 0.0f && dd > a * u);
+    }
+    return keep;
 }
 
 // Live mask of the records base[0..8), of which the first `valid` exist (the array is padded
 // so that all 8 loads are in bounds).
-template <class Ctr>
-RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 ray, float a, Ctr& ctr) {
+template <bool BEHIND, class Ctr>
+RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 ray, float a, bool fwd, Ctr& ctr) {
     float4 r[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) r[k] = base[k];
     uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) m |= bound_may_hit(r[k], src, ray, a) ? (1u << k) : 0u;
+    for (int k = 0; k < 8; ++k) m |= bound_may_hit<BEHIND>(r[k], src, ray, a, fwd) ? (1u << k) : 0u;
     ctr.bound_tests(8);
     if constexpr (Ctr::kEnabled) {
         if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true)))
@@ -289,12 +302,13 @@ RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, fl
     }
 }
 
-template <class Ctr>
+template <bool BEHIND, class Ctr>
 RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, float a,
                               float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
     const float4 hf = S.bnd[header];
     ctr.bound_tests(1);
-    if (!bound_may_hit(S.bnd[header + 1u], src, ray, a)) return;  // misses the whole run
+    const bool fwd = near >= 0.0f;
+    if (!bound_may_hit<BEHIND>(S.bnd[header + 1u], src, ray, a, fwd)) return;  // misses the whole run
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
                    off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w);
     const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
@@ -350,7 +364,7 @@ RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count,
             }
             g = g * 8u + k;  // record g*8+k of level L = group of that index one level down
             L -= 1u;
-            m = expand8(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, ray, a, ctr);
+            m = expand8<BEHIND>(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, ray, a, fwd, ctr);
         }
     }
     drain();
@@ -388,7 +402,10 @@ RT_DEV bool unwind(const uint2* my_stack, uint32_t stride, uint32_t& sp, F3 src,
     return false;
 }
 
-template <bool CULL, class Ctr>
+// CULL: 0 = every entry of every visited leaf, 1 = big sphere runs skip groups the ray's line
+// misses, 2 = also groups behind the ray's origin (worth its cost for rays that start inside
+// the scene).
+template <int CULL, class Ctr>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr) {
     RayInv ri;
@@ -439,9 +456,9 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
         if (at_leaf) {
             LeafBest lb;
             lb.init();
-            if constexpr (CULL) {
+            if constexpr (CULL != 0) {
                 if (q2.y >= CULL_MIN_SPHERES) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_spheres_lane(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                    leaf_spheres_lane<CULL == 2>(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
                     q2.y = 0u;
                 }
             }

@@ -93,8 +93,16 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
     o = oracle.OracleScene(text, build_threads=4)
     assert o.info.max_leaf > 1000  # the degenerate build this test is about
     n = 40000
-    far = rng.choice([1.5, 4.0, 60.0, 3000.0], n)[:, None]
+    far = rng.choice([0.3, 1.5, 4.0, 60.0, 3000.0], n)[:, None]
     src = offset + rng.normal(size=(n, 3)) * scale * far
+    # a third of the rays start on (just outside or just inside) a sphere's surface, as reflection,
+    # refraction and their shadow rays do: groups wholly behind the origin are skipped too
+    on = rng.random(n) < 0.33
+    start = rng.integers(0, len(c), n)
+    out = rng.normal(size=(n, 3))
+    out /= np.linalg.norm(out, axis=1, keepdims=True)
+    skin = 1.0 + rng.choice([1e-6, -1e-6, 1e-3, 0.0], n)[:, None]
+    src = np.where(on[:, None], c[start] + out * r[start, None] * skin, src)
     pick = rng.integers(0, len(c), n)
     to_c = c[pick].astype(np.float64) - src
     dist = np.linalg.norm(to_c, axis=1, keepdims=True)
@@ -107,8 +115,8 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     d *= rng.choice([1.0, 1.0, 0.01, 250.0], n)[:, None]  # shadow rays are not unit length
     src, d = src.astype(np.float32), d.astype(np.float32)
-    near = rng.choice(np.array([0.0, 1e-4], np.float32), n).astype(np.float32)
-    ignore = np.where(rng.random(n) < 0.3, pick + 1, 0xFFFFFFFF).astype(np.uint32)  # primitive 0 is the floor
+    near = rng.choice(np.array([0.0, 0.0, 1e-4, -0.25], np.float32) * np.float32(scale), n).astype(np.float32)
+    ignore = np.where(rng.random(n) < 0.3, np.where(on, start, pick) + 1, 0xFFFFFFFF).astype(np.uint32)  # primitive 0 is the floor
     wp, wd, wn = o.intersect_rays(src, d, near, ignore)
     ep, ed, en = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_EXHAUSTIVE)
     gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
