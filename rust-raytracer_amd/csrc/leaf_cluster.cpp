@@ -26,7 +26,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <cstdlib>
 #include <vector>
 
 #include "rt_host.h"
@@ -44,90 +43,132 @@ float round_up(double x) {
     return std::nextafter(f, INFINITY);
 }
 
-// {C, q} bounding entries [b, e) of v
-void bound(const std::vector<LeafSphere>& v, size_t b, size_t e, float out[4]) {
+// Radius of the smallest sphere about `c` that holds entries [b, e) of v.
+double radius_about(const std::vector<LeafSphere>& v, size_t b, size_t e, const double c[3], size_t* farthest) {
+    double R = 0.0;
+    for (size_t i = b; i < e; ++i) {
+        double d2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double d = (double)v[i].c[a] - c[a];
+            d2 += d * d;
+        }
+        const double r = std::sqrt(d2) + std::fabs((double)v[i].r);
+        if (!(r <= R)) {  // also catches NaN
+            R = r;
+            if (farthest) *farthest = i;
+        }
+    }
+    return R;
+}
+
+// Centre of a small sphere around entries [b, e): starts at the middle of their box and walks
+// towards the farthest point with a shrinking step (Badoiu-Clarkson), keeping the best centre.
+double enclose(const std::vector<LeafSphere>& v, size_t b, size_t e, double c[3], int iterations) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (size_t i = b; i < e; ++i)
         for (int a = 0; a < 3; ++a) {
             lo[a] = std::min(lo[a], (double)v[i].c[a] - std::fabs((double)v[i].r));
             hi[a] = std::max(hi[a], (double)v[i].c[a] + std::fabs((double)v[i].r));
         }
-    float C[3];
-    for (int a = 0; a < 3; ++a) C[a] = (float)(0.5 * (lo[a] + hi[a]));
-    double R = 0.0;
-    for (size_t i = b; i < e; ++i) {
-        double d2 = 0.0;
+    double cur[3];
+    for (int a = 0; a < 3; ++a) cur[a] = c[a] = 0.5 * (lo[a] + hi[a]);
+    size_t far = b;
+    double best = radius_about(v, b, e, cur, &far);
+    for (int it = 1; it <= iterations && best == best && best < 1e300; ++it) {
+        double dir[3], len = 0.0;
         for (int a = 0; a < 3; ++a) {
-            double d = (double)v[i].c[a] - (double)C[a];
-            d2 += d * d;
+            dir[a] = (double)v[far].c[a] - cur[a];
+            len += dir[a] * dir[a];
         }
-        R = std::max(R, std::sqrt(d2) + std::fabs((double)v[i].r));
+        len = std::sqrt(len);
+        const double reach = len + std::fabs((double)v[far].r);  // distance of the farthest point
+        for (int a = 0; a < 3; ++a) cur[a] += (len > 0.0 ? dir[a] / len : 0.0) * reach / (it + 1);
+        const double R = radius_about(v, b, e, cur, &far);
+        if (R < best) {
+            best = R;
+            for (int a = 0; a < 3; ++a) c[a] = cur[a];
+        }
     }
+    return best;
+}
+
+// {C, q} bounding entries [b, e) of v.  The centre is rounded to f32 first and the radius
+// taken about the rounded centre, so the record bounds what it says whatever the search did.
+void bound(const std::vector<LeafSphere>& v, size_t b, size_t e, float out[4]) {
+    double c[3];
+    enclose(v, b, e, c, 64);
+    double cf[3];
+    for (int a = 0; a < 3; ++a) {
+        out[a] = (float)c[a];
+        cf[a] = (double)out[a];
+    }
+    const double R = radius_about(v, b, e, cf, nullptr);
     const double Rp = R * (1.0 + CULL_K0) * (1.0 + 1e-6);
-    out[0] = C[0]; out[1] = C[1]; out[2] = C[2];
     out[3] = round_up(Rp * Rp * (1.0 + CULL_ALPHA));
     if (!(out[3] == out[3]) || !(R == R)) out[3] = INFINITY;  // never cull what cannot be bounded
 }
 
-// Median splits on the longest axis of the centres.  Records group entries by absolute index
-// (8i .. 8i+7, 64i .. 64i+63, ...), so the split point is the multiple of the largest group
-// size that lies inside (b, e), nearest to the middle: no group straddles a split.
-void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
-    size_t m = 0;
-    for (size_t g : {(size_t)4096, (size_t)512, (size_t)64, (size_t)8}) {
-        const size_t lo = (b / g + 1) * g;  // first multiple of g above b
-        if (lo >= e) continue;
-        const size_t mid = (b + e) / 2;
-        m = std::max(lo, (mid + g / 2) / g * g);
-        while (m >= e) m -= g;
-        break;
-    }
-    if (m <= b || m >= e) return;
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = v[b].c[a];
-    for (size_t i = b; i < e; ++i)
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], v[i].c[a]);
-            hi[a] = std::max(hi[a], v[i].c[a]);
-        }
-    int ax = 0;
-    for (int a = 1; a < 3; ++a)
-        if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
-    auto key = [ax](const LeafSphere& s) { return s.c[ax] == s.c[ax] ? s.c[ax] : INFINITY; };  // total order
-    std::nth_element(v.begin() + b, v.begin() + m, v.begin() + e, [&key](const LeafSphere& x, const LeafSphere& y) {
-        const float kx = key(x), ky = key(y);
-        if (kx != ky) return kx < ky;
-        return x.pos < y.pos;  // deterministic
-    });
-    order(v, b, m);
-    order(v, m, e);
+// Cost of keeping entries [b, e) in one group: a ray's chance of passing a bounding sphere goes
+// with its cross-section, and passing costs work in proportion to the entries inside.
+double group_cost(const std::vector<LeafSphere>& v, size_t b, size_t e) {
+    double c[3];
+    const double R = enclose(v, b, e, c, 0);
+    return R * R * (double)(e - b);
 }
 
-// Spheres of very different size make poor neighbours: one big sphere inflates the bound of
-// every group it sits in.  The run is therefore cut into segments of similar radius (largest
-// first, a new segment when the radius has halved), each padded to a multiple of 8 entries
-// with copies of its last sphere and ordered spatially on its own.
-void arrange(std::vector<LeafSphere>& v) {
-    static const float CLASS_RATIO = getenv("RT_CLASS_RATIO") ? (float)atof(getenv("RT_CLASS_RATIO")) : 0.0f;
-    auto size_of = [](const LeafSphere& s) { const float r = std::fabs(s.r); return r == r ? r : INFINITY; };
-    std::stable_sort(v.begin(), v.end(), [&](const LeafSphere& x, const LeafSphere& y) { return size_of(x) > size_of(y); });
-    std::vector<LeafSphere> out;
-    out.reserve(v.size() + 64);
-    size_t i = 0;
-    while (i < v.size()) {
-        const size_t b = out.size();
-        const float r0 = size_of(v[i]);
-        size_t j = i;
-        while (j < v.size() && (j - i < 8 || size_of(v[j]) >= CLASS_RATIO * r0)) ++j;
-        out.insert(out.end(), v.begin() + i, v.begin() + j);
-        while (out.size() % 8) {  // a copy never wins: same distance as its original, later position
-            out.push_back(out.back());
-            out.back().pos |= 0x80000000u;
+// Recursive two-way splits.  Records group entries by absolute index (8i .. 8i+7, 64i .. 64i+63,
+// ...), so split points are multiples of the largest group size that has one inside (b, e): no
+// group of that size straddles a split.  Among the three axes (entries sorted by centre) and up
+// to 15 such points around the middle, the split with the least summed cost wins.
+void order(std::vector<LeafSphere>& v, size_t b, size_t e) {
+    size_t g = 0, first = 0;
+    for (size_t cand : {(size_t)4096, (size_t)512, (size_t)64, (size_t)8}) {
+        first = (b / cand + 1) * cand;  // first multiple above b
+        if (first < e) {
+            g = cand;
+            break;
         }
-        order(out, b, out.size());
-        i = j;
     }
-    v.swap(out);
+    if (g == 0) return;
+    std::vector<size_t> points;
+    for (size_t m = first; m < e; m += g) points.push_back(m);
+    if (points.size() > 15) {  // keep 15 evenly spread
+        std::vector<size_t> some;
+        for (int k = 0; k < 15; ++k) some.push_back(points[(points.size() - 1) * k / 14]);
+        points.swap(some);
+    }
+    std::vector<LeafSphere> best_order;
+    double best = INFINITY;
+    size_t best_m = points[points.size() / 2];
+    std::vector<LeafSphere> tmp(v.begin() + b, v.begin() + e);
+    for (int ax = 0; ax < 3; ++ax) {
+        auto key = [ax](const LeafSphere& s) { return s.c[ax] == s.c[ax] ? s.c[ax] : INFINITY; };  // total order
+        std::sort(tmp.begin(), tmp.end(), [&key](const LeafSphere& x, const LeafSphere& y) {
+            const float kx = key(x), ky = key(y);
+            if (kx != ky) return kx < ky;
+            return x.pos < y.pos;  // deterministic
+        });
+        for (size_t m : points) {
+            const double cost = group_cost(tmp, 0, m - b) + group_cost(tmp, m - b, e - b);
+            if (cost < best) {
+                best = cost;
+                best_m = m;
+                best_order = tmp;
+            }
+        }
+    }
+    if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), v.begin() + b);
+    order(v, b, best_m);
+    order(v, best_m, e);
+}
+
+// Pads the run to a multiple of 8 entries with copies of its last sphere, then orders it.
+void arrange(std::vector<LeafSphere>& v) {
+    while (v.size() % 8) {  // a copy never wins: same distance as its original, later position
+        v.push_back(v.back());
+        v.back().pos |= 0x80000000u;
+    }
+    order(v, 0, v.size());
 }
 
 }  // namespace
