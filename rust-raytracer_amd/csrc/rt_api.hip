@@ -56,7 +56,7 @@ struct rt_context {
     DevBuf<uint2> node_sh;
     size_t shadow_cap = 0;
     DevBuf<uint4> node_kid;
-    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_base[RT_MAX_LEVELS + 1] | shadow_total | overflow
+    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_count[RT_MAX_LEVELS] | overflow
     DevBuf<uint32_t> levels;
     DevBuf<unsigned long long> counters;
     size_t pool_cap = 0;
@@ -84,8 +84,8 @@ struct rt_scene {
 
 namespace {
 
-constexpr uint32_t LV_SHADOW_BASE = 2 * RT_MAX_LEVELS, LV_SHADOW_TOTAL = 3 * RT_MAX_LEVELS + 1,
-                   LV_OVERFLOW = 3 * RT_MAX_LEVELS + 2, LV_WORDS = 3 * RT_MAX_LEVELS + 3;
+constexpr uint32_t LV_SHADOW_COUNT = 2 * RT_MAX_LEVELS, LV_OVERFLOW = 3 * RT_MAX_LEVELS, LV_WORDS = 3 * RT_MAX_LEVELS + 1;
+constexpr uint32_t SHADOW_GROUP_FROM = 4;  // levels from here on are too small to fill the GPU: one shadow launch for all
 
 int fail(rt_context* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -420,8 +420,7 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         A.shadow_cap = (uint32_t)(ctx->shadow_cap / lights1);
         A.level_count = ctx->levels.p;
         A.level_base = ctx->levels.p + RT_MAX_LEVELS;
-        A.shadow_base = ctx->levels.p + LV_SHADOW_BASE;
-        A.shadow_total = ctx->levels.p + LV_SHADOW_TOTAL;
+        A.shadow_count = ctx->levels.p + LV_SHADOW_COUNT;
         A.overflow = ctx->levels.p + LV_OVERFLOW;
         A.counters = ctx->counters.p;
 
@@ -435,22 +434,30 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         const uint32_t gridn = std::min<uint32_t>(grid0, 16384);
         const uint32_t grids = std::min<uint32_t>(grid0, 65535);  // per light: the launch is (grids, n_lights)
         hipStream_t st2 = ctx->shadow_stream;
+        auto shadow_and_light = [&](uint32_t first, uint32_t last) -> int {
+            const uint32_t gs = first == 0 ? grids : gridn, gl = first == 0 ? grid0 : gridn;
+            RT_HIP(ctx, hipStreamWaitEvent(st2, ctx->ev_level[last], 0));
+            RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2)
+                             : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
+            RT_HIP(ctx, fast ? rt_fast::launch_light(A, first, last, work, gl, st2)
+                             : rt_exact::launch_light(A, first, last, work, gl, st2));
+            return RT_OK;
+        };
         for (uint32_t level = 0; level <= opt->max_depth; ++level) {
             const uint32_t g = level == 0 ? grid0 : gridn;
             RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
-            RT_HIP(ctx, fast ? rt_fast::launch_spawn(A, level, g, st) : rt_exact::launch_spawn(A, level, g, st));
-            if (n_lights) {  // this level's shadow rays: beside the next levels, on the second stream
+            if (n_lights) {  // this level's shadow rays and lighting: beside the next levels, on the second stream
                 RT_HIP(ctx, hipEventRecord(ctx->ev_level[level], st));
-                RT_HIP(ctx, hipStreamWaitEvent(st2, ctx->ev_level[level], 0));
-                RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn, st2)
-                                 : rt_exact::launch_shadow(A, level, work, cull, level == 0 ? grids : gridn, st2));
+                if (level < SHADOW_GROUP_FROM || level == opt->max_depth) {
+                    const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
+                    rc = shadow_and_light(first, level);
+                    if (rc != RT_OK) return rc;
+                }
             }
         }
         if (n_lights) {
             RT_HIP(ctx, hipEventRecord(ctx->ev_shadow, st2));
             RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_shadow, 0));
-            RT_HIP(ctx, fast ? rt_fast::launch_light(A, opt->max_depth, work, grid0 * 2, st)
-                             : rt_exact::launch_light(A, opt->max_depth, work, grid0 * 2, st));
         }
         RT_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         for (uint32_t level = opt->max_depth + 1; level-- > 0;) {
@@ -463,7 +470,8 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         RT_HIP(ctx, hipMemcpy(lv, ctx->levels.p, sizeof(lv), hipMemcpyDeviceToHost));
         if (lv[LV_OVERFLOW] != 0) {  // a pool overflowed: grow and run the frame again
             uint64_t need = n_slots;
-            const uint64_t sneed = lv[LV_SHADOW_TOTAL];
+            uint64_t sneed = 0;
+            for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed += lv[LV_SHADOW_COUNT + l];
             for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
             if (need > ctx->pool_cap) cap = std::max<size_t>(ctx->pool_cap * 2, (size_t)need + (need >> 2));
             if (sneed > A.shadow_cap) scap = std::max<size_t>((size_t)A.shadow_cap * 2, (size_t)sneed + (sneed >> 2));
@@ -475,7 +483,8 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
         unsigned long long c[20];
         RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         stats.rays_primary = n_primary;
-        stats.rays_shadow = (uint64_t)lv[LV_SHADOW_TOTAL] * n_lights;
+        stats.rays_shadow = 0;
+        for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += (uint64_t)lv[LV_SHADOW_COUNT + l] * n_lights;
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
         for (int k = 0; k < 16; ++k) stats.work[k] = c[4 + k];

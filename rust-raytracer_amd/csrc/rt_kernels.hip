@@ -6,15 +6,17 @@
 // ray owns one node in a pool (node index = ray index).  Per level, on the frame's stream:
 //   k_intersect  closest hit of every ray of the level (src/scene.rs:90); for each front-face
 //                hit it appends one shadow ray per light (src/scene.rs:103-112) to the frame's
-//                shadow queue with a wave-wide ballot + prefix count and one atomic per wave;
-//   k_spawn      appends the reflection / refraction rays the hits spawn (src/scene.rs:127-193)
-//                to level d+1, again by ballot + prefix count.
+//                shadow queues, and the reflection / refraction rays the hit spawns
+//                (src/scene.rs:127-193) to level d+1, both with a wave-wide ballot + prefix
+//                count and one atomic per wave.
 // The shadow rays of a level do not feed the next level, so they are traced on a second
-// stream while the next levels' (ever smaller) launches run:
-//   k_shadow     closest hit of every shadow ray of one level -> blocked flag (src/scene.rs:108-117).
+// stream while the next levels' (ever smaller) launches run; the deepest levels, which are too
+// small to fill the GPU, share one launch:
+//   k_shadow     closest hit of every shadow ray of a range of levels -> blocked flag
+//                (src/scene.rs:108-117);
+//   k_light      direct lighting of the nodes of those levels from their unblocked lights, in
+//                light order (src/scene.rs:119-124).
 // When both streams are done:
-//   k_light      direct lighting of every node from its unblocked lights, in light order
-//                (src/scene.rs:119-124);
 //   k_resolve    from the deepest level up: total = direct + refl * reflectance + refr *
 //                transmittance in that order, clamped per node exactly as src/scene.rs:195 does
 //                before the parent multiplies it -- the clamp makes the recursion non-linear, so
@@ -120,8 +122,15 @@ RT_DEV bool fetch_ray(const FrameArgs& A, uint32_t i, uint32_t node, Ray& r) {
     return true;
 }
 
+// First shadow-queue slot of `level`: the lit hits of all earlier levels (complete by now).
+RT_DEV uint32_t shadow_first(const FrameArgs& A, uint32_t level) {
+    uint32_t s = 0;
+    for (uint32_t j = 0; j < level; ++j) s += A.shadow_count[j];
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------
-// k_intersect: closest hit of every ray of one level + its shadow rays
+// k_intersect: closest hit of every ray of one level, its shadow rays, and the rays it spawns
 // ---------------------------------------------------------------------------------------
 template <bool LEVEL0, int CULL, class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArgs A, uint32_t level) {
@@ -129,9 +138,12 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
     const DevScene& S = A.scene;
     const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
     const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = base + count;
+    const uint32_t next_base = base + count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = next_base;
     const uint32_t n_lights = S.n_lights;
+    const uint32_t sh_base = shadow_first(A, level);
     Ctr ctr;
+    uint32_t n_refl = 0, n_refr = 0;
 
     for (uint32_t chunk = blockIdx.x * RT_BLOCK; chunk < count; chunk += gridDim.x * RT_BLOCK) {
         const uint32_t i = chunk + threadIdx.x;
@@ -141,18 +153,21 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
         const bool active = i < count && fetch_ray<LEVEL0>(A, i, node, ray);
 
         bool lit = false;  // front-face hit: needs its shadow rays
+        bool is_hit = false;
         Hit hit;
         hit.dist = 0.0f; hit.prim = NO_PRIM; hit.n = f3(0, 0, 0);
         if (active) {
-            const bool ok = kd_traverse_closest<CULL>(S, ray.src, ray.dir, ray.near, ray.ignore, hit, lds_stack, ctr);
-            if (!ok) hit.prim = NO_PRIM;
+            is_hit = kd_traverse_closest<CULL>(S, ray.src, ray.dir, ray.near, ray.ignore, hit, lds_stack, ctr);
+            if (!is_hit) hit.prim = NO_PRIM;
             A.hit_a[node] = make_float4(hit.n.x, hit.n.y, hit.n.z, hit.dist);
             A.hit_p[node] = hit.prim;
-            if (ok) {
+            if (is_hit) {
                 ctr.surface_hits(1);
                 lit = !(dot(hit.n, ray.dir) > 0.0f) && n_lights > 0;  // src/scene.rs:96, :102
             }
         }
+        const F3 pos = add(ray.src, mul(ray.dir, hit.dist));  // src/scene.rs:95
+
         // ---- one shadow ray per light for every front-face hit.  Each light has its own queue
         // (a slice of the arrays, shadow_cap slots long) and a hit uses the same slot in all of
         // them, so that 64 consecutive slots of a queue are rays towards one light from
@@ -161,7 +176,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
         const uint32_t c_lit = (uint32_t)__popcll(m_lit);
         if (c_lit) {
             uint32_t slot0 = 0;
-            if (lane_id() == 0) slot0 = atomicAdd(A.shadow_total, c_lit);
+            if (lane_id() == 0) slot0 = sh_base + atomicAdd(&A.shadow_count[level], c_lit);
             slot0 = __builtin_amdgcn_readfirstlane(slot0);
             if (lit) {
                 const uint32_t first = slot0 + prefix_count(m_lit);
@@ -169,8 +184,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
                 if (!fits) *A.overflow = 1u;
                 A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
                 if (fits) {
-                    const F3 pos = add(ray.src, mul(ray.dir, hit.dist));  // src/scene.rs:95
-                    for (uint32_t l = 0; l < n_lights; ++l) {             // src/scene.rs:103-112
+                    for (uint32_t l = 0; l < n_lights; ++l) {  // src/scene.rs:103-112
                         ctr.light_evals(1);
                         const float4 lp = S.lights[l * 2];
                         const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
@@ -184,99 +198,33 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
             }
         }
         if (i < count && !lit) A.node_sh[node] = make_uint2(NONE, 0u);  // also the padding slots of edge tiles
-    }
-    flush_work(A, ctr);
-}
 
-// ---------------------------------------------------------------------------------------
-// k_shadow: is anything between the surface point and the light (src/scene.rs:108-117):
-// a full closest-hit query ignoring the surface's own primitive, blocked iff its distance
-// <= the light's distance.
-// ---------------------------------------------------------------------------------------
-template <int CULL, class Ctr>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A, uint32_t level) {
-    extern __shared__ uint2 lds_stack[];
-    const DevScene& S = A.scene;
-    const uint32_t first = A.shadow_base[level], end = A.shadow_base[level + 1];  // clamped to the queue's size
-    const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;                   // blockIdx.y = light
-    Ctr ctr;
-    for (uint32_t k = first + blockIdx.x * RT_BLOCK + threadIdx.x; k < end; k += gridDim.x * RT_BLOCK) {
-        const uint64_t i = queue + k;
-        const float4 so = A.sray_o[i];
-        const float4 sd = A.sray_d[i];
-        Hit blocker;
-        bool blocked = false;
-        if (kd_traverse_closest<CULL>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
-                                lds_stack, ctr))
-            blocked = blocker.dist <= so.w;
-        A.sray_blocked[i] = blocked ? 1u : 0u;
-    }
-    flush_work(A, ctr);
-}
-
-// ---------------------------------------------------------------------------------------
-// k_spawn: the next level's rays.  Leaves in the node: {background or 0, reflectance weight}
-// and the child links; k_light adds the direct light later.
-// ---------------------------------------------------------------------------------------
-template <bool LEVEL0>
-__global__ void __launch_bounds__(RT_BLOCK) k_spawn(FrameArgs A, uint32_t level) {
-    const DevScene& S = A.scene;
-    const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
-    const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
-    const uint32_t next_base = base + count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // k_intersect of this level is complete: its shadow rays end here
-        const uint32_t t = *A.shadow_total;
-        A.shadow_base[level + 1] = t < A.shadow_cap ? t : A.shadow_cap;
-    }
-    uint32_t n_refl = 0, n_refr = 0;
-
-    for (uint32_t chunk = blockIdx.x * RT_BLOCK; chunk < count; chunk += gridDim.x * RT_BLOCK) {
-        const uint32_t i = chunk + threadIdx.x;
-        const uint32_t node = base + i;
-        Ray ray;
-        ray.src = f3(0, 0, 0); ray.dir = f3(1, 0, 0); ray.near = 0.0f; ray.contribution = 0.0f; ray.ignore = NO_PRIM;
-        const bool active = i < count && fetch_ray<LEVEL0>(A, i, node, ray);
-
-        F3 total = f3(0.0f, 0.0f, 0.0f);
-        bool want_refl = false, want_refr = false, is_hit = false;
-        F3 refl_ray = f3(0, 0, 0), refr_ray = f3(0, 0, 0), pos = f3(0, 0, 0);
+        // ---- the rays this hit spawns (src/scene.rs:127-193); the node keeps {background or 0,
+        // reflectance weight} and the child links, k_light adds the direct light later
+        bool want_refl = false, want_refr = false;
+        F3 refl_ray = f3(0, 0, 0), refr_ray = f3(0, 0, 0);
         float reflectance = 0.0f, transmittance = 0.0f, refl_contrib = 0.0f, refr_contrib = 0.0f;
-        uint32_t hit_prim = NO_PRIM;
-
-        if (active) {
-            hit_prim = A.hit_p[node];
-            if (hit_prim != NO_PRIM) {
-                is_hit = true;
-                if (level < A.max_depth) {
-                    const float4 ha = A.hit_a[node];
-                    const F3 normal = f3(ha.x, ha.y, ha.z);
-                    const Surface surf = load_surface(S, S.prim_surface[hit_prim]);
-                    pos = add(ray.src, mul(ray.dir, ha.w));               // src/scene.rs:95
-                    const bool back_face = dot(normal, ray.dir) > 0.0f;   // :96
-                    if (!back_face) {  // :127-144
-                        refl_contrib = ray.contribution * surf.reflectance;
-                        if (refl_contrib > A.min_contribution) {
-                            want_refl = true;
-                            refl_ray = reflect(ray.dir, normal);
-                            reflectance = surf.reflectance;
-                        }
-                    }
-                    // :147-193
-                    if (back_face) transmittance = surf.transmittance > A.min_contribution ? 1.0f : 0.0f;
-                    else transmittance = surf.transmittance;
-                    refr_contrib = ray.contribution * transmittance;
-                    if (refr_contrib > A.min_contribution) {
-                        want_refr = true;
-                        refr_ray = back_face ? refract(ray.dir, neg(normal), 1.0f / surf.ior)
-                                             : refract(ray.dir, normal, surf.ior);
-                    }
+        if (is_hit && level < A.max_depth) {
+            const Surface surf = load_surface(S, S.prim_surface[hit.prim]);
+            const bool back_face = dot(hit.n, ray.dir) > 0.0f;  // :96
+            if (!back_face) {  // :127-144
+                refl_contrib = ray.contribution * surf.reflectance;
+                if (refl_contrib > A.min_contribution) {
+                    want_refl = true;
+                    refl_ray = reflect(ray.dir, hit.n);
+                    reflectance = surf.reflectance;
                 }
-            } else {
-                total = f3(S.bg[0], S.bg[1], S.bg[2]);  // :199, never clamped
+            }
+            // :147-193
+            if (back_face) transmittance = surf.transmittance > A.min_contribution ? 1.0f : 0.0f;
+            else transmittance = surf.transmittance;
+            refr_contrib = ray.contribution * transmittance;
+            if (refr_contrib > A.min_contribution) {
+                want_refr = true;
+                refr_ray = back_face ? refract(ray.dir, neg(hit.n), 1.0f / surf.ior) : refract(ray.dir, hit.n, surf.ior);
             }
         }
-
-        // ---- append the spawned rays to the next level: reflection slots first, then refraction
+        // append to the next level: reflection slots first, then refraction
         const uint64_t m_refl = __ballot(want_refl);
         const uint64_t m_refr = __ballot(want_refr);
         const uint32_t c_refl = (uint32_t)__popcll(m_refl), c_refr = (uint32_t)__popcll(m_refr);
@@ -295,7 +243,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_spawn(FrameArgs A, uint32_t level)
         if (want_refl) {
             ++n_refl;
             A.ray_o[refl_idx] = make_float4(pos.x, pos.y, pos.z, refl_contrib);
-            A.ray_d[refl_idx] = make_float4(refl_ray.x, refl_ray.y, refl_ray.z, __uint_as_float(hit_prim));
+            A.ray_d[refl_idx] = make_float4(refl_ray.x, refl_ray.y, refl_ray.z, __uint_as_float(hit.prim));
         }
         if (want_refr) {
             ++n_refr;
@@ -303,28 +251,58 @@ __global__ void __launch_bounds__(RT_BLOCK) k_spawn(FrameArgs A, uint32_t level)
             A.ray_d[refr_idx] = make_float4(refr_ray.x, refr_ray.y, refr_ray.z, __uint_as_float(NO_PRIM));
         }
         if (active) {
+            const F3 total = is_hit ? f3(0.0f, 0.0f, 0.0f) : f3(S.bg[0], S.bg[1], S.bg[2]);  // :199, never clamped
             A.node_col[node] = make_float4(total.x, total.y, total.z, reflectance);
             A.node_kid[node] = make_uint4(refl_idx, refr_idx, __float_as_uint(transmittance), is_hit ? 1u : 0u);
         }
     }
-
     const uint32_t s_refl = wave_sum(n_refl), s_refr = wave_sum(n_refr);
     if (lane_id() == 0) {
         if (s_refl) atomicAdd(&A.counters[2], (unsigned long long)s_refl);
         if (s_refr) atomicAdd(&A.counters[3], (unsigned long long)s_refr);
     }
+    flush_work(A, ctr);
 }
 
 // ---------------------------------------------------------------------------------------
-// k_light: direct lighting of every node of the frame (all levels in one launch), once the
-// shadow rays are traced.
+// k_shadow: is anything between the surface point and the light (src/scene.rs:108-117):
+// a full closest-hit query ignoring the surface's own primitive, blocked iff its distance
+// <= the light's distance.
+// ---------------------------------------------------------------------------------------
+template <int CULL, class Ctr>
+__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A, uint32_t first_level, uint32_t last_level) {
+    extern __shared__ uint2 lds_stack[];
+    const DevScene& S = A.scene;
+    const uint32_t first = shadow_first(A, first_level);
+    uint32_t end = shadow_first(A, last_level + 1);
+    end = end < A.shadow_cap ? end : A.shadow_cap;
+    const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
+    Ctr ctr;
+    for (uint32_t k = first + blockIdx.x * RT_BLOCK + threadIdx.x; k < end; k += gridDim.x * RT_BLOCK) {
+        const uint64_t i = queue + k;
+        const float4 so = A.sray_o[i];
+        const float4 sd = A.sray_d[i];
+        Hit blocker;
+        bool blocked = false;
+        if (kd_traverse_closest<CULL>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
+                                lds_stack, ctr))
+            blocked = blocker.dist <= so.w;
+        A.sray_blocked[i] = blocked ? 1u : 0u;
+    }
+    flush_work(A, ctr);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_light: direct lighting of the nodes of levels first_level .. last_level, once their shadow
+// rays are traced.
 // ---------------------------------------------------------------------------------------
 template <class Ctr>
-__global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t last_level) {
+__global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t first_level, uint32_t last_level) {
     const DevScene& S = A.scene;
-    const uint32_t n_nodes = A.level_base[last_level + 1];  // end of the deepest level
+    const uint32_t first = first_level == 0 ? 0u : A.level_base[first_level];
+    const uint32_t end = A.level_base[last_level + 1];  // both already clamped to the pool
     Ctr ctr;
-    for (uint32_t node = blockIdx.x * RT_BLOCK + threadIdx.x; node < n_nodes; node += gridDim.x * RT_BLOCK) {
+    for (uint32_t node = first + blockIdx.x * RT_BLOCK + threadIdx.x; node < end; node += gridDim.x * RT_BLOCK) {
         const uint2 sh = A.node_sh[node];
         if (sh.x == NONE) continue;  // miss, back face, padding slot, or no lights
         const uint32_t hit_prim = A.hit_p[node];
@@ -562,31 +540,27 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
     return hipGetLastError();
 }
 
-hipError_t launch_shadow(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
+hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, uint32_t grid,
+                         hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
     const dim3 g(grid, A.scene.n_lights), b(RT_BLOCK);
-    const int mode = !cull ? 0 : (level == 0 ? 1 : 2);  // deeper levels' hits lie among the spheres
+    const int mode = !cull ? 0 : (first_level == 0 ? 1 : 2);  // deeper levels' hits lie among the spheres
     if (work) {
-        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, level);
-        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, WorkCounters>), g, b, lds, st, A, level);
-        else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, level);
+        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level);
+        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, WorkCounters>), g, b, lds, st, A, first_level, last_level);
+        else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, first_level, last_level);
     } else {
-        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, level);
-        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, NoCounters>), g, b, lds, st, A, level);
-        else hipLaunchKernelGGL((k_shadow<0, NoCounters>), g, b, lds, st, A, level);
+        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, first_level, last_level);
+        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, NoCounters>), g, b, lds, st, A, first_level, last_level);
+        else hipLaunchKernelGGL((k_shadow<0, NoCounters>), g, b, lds, st, A, first_level, last_level);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_spawn(const FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st) {
-    if (level == 0) hipLaunchKernelGGL((k_spawn<true>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
-    else hipLaunchKernelGGL((k_spawn<false>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
-    return hipGetLastError();
-}
-
-hipError_t launch_light(const FrameArgs& A, uint32_t last_level, bool work, uint32_t grid, hipStream_t st) {
-    if (work) hipLaunchKernelGGL((k_light<WorkCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, last_level);
-    else hipLaunchKernelGGL((k_light<NoCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, last_level);
+hipError_t launch_light(const FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, uint32_t grid,
+                        hipStream_t st) {
+    if (work) hipLaunchKernelGGL((k_light<WorkCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, first_level, last_level);
+    else hipLaunchKernelGGL((k_light<NoCounters>), dim3(grid), dim3(RT_BLOCK), 0, st, A, first_level, last_level);
     return hipGetLastError();
 }
 

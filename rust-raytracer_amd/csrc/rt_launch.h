@@ -60,8 +60,8 @@ struct FrameArgs {
     float4* sray_d;         // direction.xyz, bits(ignored primitive)
     uint32_t* sray_blocked; // 1 = a primitive lies between the surface and the light
     uint32_t shadow_cap;    // slots per light's queue; light l owns [l * shadow_cap, (l + 1) * shadow_cap)
-    uint32_t* shadow_total; // lit hits so far in this frame (each takes one slot in every queue)
-    uint32_t* shadow_base;  // [RT_MAX_LEVELS + 1] first slot of each level's shadow rays
+    uint32_t* shadow_count; // [RT_MAX_LEVELS] lit hits of each level (each takes one slot in every queue);
+                            // a level's slots follow those of the levels before it
     uint32_t* overflow;
     unsigned long long* counters;  // [17]: primary, shadow, reflect, refract, then the 13 work counters
     // outputs (either may be null)
@@ -82,9 +82,10 @@ struct DeinterleaveArgs {
     namespace NS {                                                                                                   \
     hipError_t init_kernels();                                                                                       \
     hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st); \
-    hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st); \
-    hipError_t launch_spawn(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);               \
-    hipError_t launch_light(const rtamd::FrameArgs& A, uint32_t last_level, bool work, uint32_t grid, hipStream_t st); \
+    hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, \
+                             uint32_t grid, hipStream_t st);                                                         \
+    hipError_t launch_light(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work,         \
+                            uint32_t grid, hipStream_t st);                                                          \
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
     hipError_t launch_debug_intersect(const rtamd::DevScene& S, bool cull, uint64_t n, const float* src, const float* ray, \
