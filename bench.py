@@ -60,6 +60,10 @@ RAY_STATE_BYTES = 2 * 64   # one 32-byte ray record + one 32-byte node record, w
 FRAMEBUFFER_BYTES = 3      # u8 RGB per pixel
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+# Plain (not packed, not fused) f32 vector instructions issue one wave64 instruction per SIMD every
+# 4 cycles: 256 CUs x 64 lanes x 2.4 GHz lane-operations per second.  The parity mode may neither
+# fuse nor pack the reference's arithmetic, so this is the ceiling its counted operations can reach.
+PEAK_PLAIN_TOPS = 39.3
 
 
 def parse_args():
@@ -206,7 +210,7 @@ def main():
                      "device_frame": round(float(mx[8]), 4), "step_wall": round(ms_per_step, 4)},
         "roofline": {
             "bound": "valu",
-            "kernel": "k_trace (all bounce levels of one frame)",
+            "kernel": "trace phase of one frame: k_intersect + k_shadow + k_light of every bounce level, two streams",
             "achieved": round(flops / trace_s / 1e12, 4),
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",
@@ -217,6 +221,11 @@ def main():
             "hbm_achieved_GBs": round(abytes / trace_s / 1e9, 3),
             "hbm_peak_GBs": PEAK_HBM_GBS,
             "hbm_frac": round(abytes / trace_s / 1e9 / PEAK_HBM_GBS, 6),
+            "plain_op_ceiling": {"achieved": round(flops / trace_s / 1e12, 4), "peak": PEAK_PLAIN_TOPS, "unit": "Tops/s",
+                                 "frac": round(flops / trace_s / 1e12 / PEAK_PLAIN_TOPS, 5)},
+            "walk_lane_use": round((work["bound_tests"] + work["sphere_tests"]) / work["lane_slots"], 4)
+                             if work.get("lane_slots") else None,
+            "reference_equivalent_TFLOPs": round(sum(ref_work[k] * c for k, c in FLOP.items()) / trace_s / 1e12, 2),
             "work": {k: int(v) for k, v in work.items()},
             "reference_work": {k: int(ref_work[k]) for k in ("node_visits", "sphere_tests", "cone_tests", "poly_tests")},
             "reference_flops_per_frame": sum(ref_work[k] * c for k, c in FLOP.items()),
