@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtamd.so")
+LIB_PATH = os.environ.get("RTAMD_LIB", os.path.join(_HERE, "librtamd.so"))  # RTAMD_LIB: another build of the library
 
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_BUILD, RT_ERR_PARSE, RT_ERR_IO, RT_ERR_CAPACITY = (

@@ -88,7 +88,7 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
     reference's f32 discriminant accepts rays that geometrically miss."""
     rng = np.random.default_rng(11)
     offset = np.array(offset, np.float64)
-    text, c, r = sphere_cloud(rng, 6000, scale, offset)
+    text, c, r = sphere_cloud(rng, 6003, scale, offset)  # not a multiple of 8: the run gets padding copies
     sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
     o = oracle.OracleScene(text, build_threads=4)
     assert o.info.max_leaf > 1000  # the degenerate build this test is about
