@@ -173,6 +173,85 @@ void arrange(std::vector<LeafSphere>& v) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------
+// Polygons.  What the reference can accept (src/polygon.rs:58-293, restated in rt_shapes.h
+// isect_polygon): with gn = fl((v1-v0) x (v2-v0)), t = fl(fl((v0-src).gn) / fl(ray.gn)) >= near
+// and P = fl(src + ray t), the crossing test only passes if P's two kept coordinates lie in
+// the polygon's coordinate ranges (a crossing edge has scale in [0,1], and P's major
+// coordinate lies between two crossing points), each up to 8u(M + |src| + |X - src|), where
+// X = src + ray t exactly -- a point of the ray's LINE -- and M bounds the vertex coordinates.
+// The dropped coordinate D is the one where |gn| is largest, and (X - v0).gn is a rounding
+// residue of at most u |gn| (5|v0 - src| + 3|X - src|), so
+//     |X_D - v0_D| <= |gn_m/gn_D| |X_m - v0_m| + |gn_M/gn_D| |X_M - v0_M| + sqrt(3) residue/|gn|,
+// whatever the quality of gn (the ratios are at most 1).  X therefore lies in a box: the
+// polygon's ranges on the kept axes and v0_D +- h on the dropped one, all widened by at most
+// 32u (M + |src| + |X - src| + |v0 - src|).  With C the box's centre and R its half diagonal
+// this gives  |X - C| <= R (1 + 2e-5) + 2e-5 |C| + 1.1e-5 |src - C|,  the form the sphere
+// hierarchy's test is built for (its margins are wider than these).  Which axis is dropped is
+// decided here in binary64 with the worst f32 deviation of either kernel build (plain or fused
+// multiply-add) as a dead band; inside the band every axis is allowed for.
+// ---------------------------------------------------------------------------------------
+bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, float c_out[3], float* r_out) {
+    const double u = 5.9604644775390625e-8;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = 0; i < count; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const double x = vertices[first + i].point[a];
+            if (!(std::fabs(x) < 1e30)) return false;
+            lo[a] = std::min(lo[a], x);
+            hi[a] = std::max(hi[a], x);
+        }
+    const float* p0 = vertices[first].point;
+    const float* p1 = vertices[first + 1].point;
+    const float* p2 = vertices[first + 2].point;
+    double ea[3], eb[3];
+    for (int a = 0; a < 3; ++a) {
+        ea[a] = (double)(float)((double)p1[a] - (double)p0[a]);  // the kernels' f32 edge vectors
+        eb[a] = (double)(float)((double)p2[a] - (double)p0[a]);
+    }
+    const double g[3] = {ea[1] * eb[2] - ea[2] * eb[1], ea[2] * eb[0] - ea[0] * eb[2], ea[0] * eb[1] - ea[1] * eb[0]};
+    const double la = std::sqrt(ea[0] * ea[0] + ea[1] * ea[1] + ea[2] * ea[2]);
+    const double lb = std::sqrt(eb[0] * eb[0] + eb[1] * eb[1] + eb[2] * eb[2]);
+    const double noise = 4.0 * u * la * lb;  // |kernel's gn - g| per component, either build
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&g](int x, int y) { return std::fabs(g[x]) > std::fabs(g[y]); });
+    const bool clear = std::fabs(g[order[0]]) - std::fabs(g[order[1]]) > 4.0 * noise && std::fabs(g[order[0]]) > 8.0 * noise;
+    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};  // union of the allowed boxes
+    for (int D = 0; D < 3; ++D) {
+        if (clear && D != order[0]) continue;
+        const int m = (D + 1) % 3, M = (D + 2) % 3;
+        double rm = 1.0, rM = 1.0;
+        if (clear) {
+            rm = std::min(1.0, (std::fabs(g[m]) + noise) / (std::fabs(g[D]) - noise));
+            rM = std::min(1.0, (std::fabs(g[M]) + noise) / (std::fabs(g[D]) - noise));
+        }
+        const double Em = std::max(std::fabs(lo[m] - p0[m]), std::fabs(hi[m] - p0[m]));
+        const double EM = std::max(std::fabs(lo[M] - p0[M]), std::fabs(hi[M] - p0[M]));
+        const double h = rm * Em + rM * EM;
+        double l3[3], h3[3];
+        l3[m] = lo[m]; h3[m] = hi[m];
+        l3[M] = lo[M]; h3[M] = hi[M];
+        l3[D] = std::min(lo[D], (double)p0[D] - h);  // (the vertices themselves stay inside too)
+        h3[D] = std::max(hi[D], (double)p0[D] + h);
+        for (int a = 0; a < 3; ++a) {
+            blo[a] = std::min(blo[a], l3[a]);
+            bhi[a] = std::max(bhi[a], h3[a]);
+        }
+    }
+    double cc[3], R = 0.0, cn = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        c_out[a] = (float)(0.5 * (blo[a] + bhi[a]));
+        cc[a] = c_out[a];
+        const double half = std::max(bhi[a] - cc[a], cc[a] - blo[a]);
+        R += half * half;
+        cn += cc[a] * cc[a];
+    }
+    R = std::sqrt(R);
+    const double Rp = R * (1.0 + 2e-5) + 2e-5 * std::sqrt(cn);
+    *r_out = round_up(Rp);
+    return Rp == Rp && *r_out < 1e30f;
+}
+
 // Block layout in `bnd` (4 floats per record, indices in records):
 //   [h]            header, as integers: {first level-2 record, first level-3, first level-4, top level}
 //   [h+1]          one record bounding the whole run

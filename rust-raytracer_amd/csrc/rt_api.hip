@@ -216,6 +216,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     std::vector<uint2> sph_id;
     std::vector<float> bnd;  // 4 floats per record
     std::vector<uint4> cone_items, poly_items;
+    bool any_poly_walk = false;
     for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
         const rt_kd_node& n = sc->tree.nodes[ni];
         if (n.axis != 3) {
@@ -224,19 +225,30 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             continue;
         }
         const uint32_t s0 = (uint32_t)sph.size(), c0 = (uint32_t)cone_items.size(), p0 = (uint32_t)poly_items.size();
-        std::vector<LeafSphere> ls;
+        std::vector<LeafSphere> ls, lp;
+        bool poly_bounds = true;
         for (uint32_t k = 0; k < n.over; ++k) {
             const uint32_t prim = sc->tree.refs[n.under + k];
             const rt_primitive& p = sd.primitives[prim];
             if (p.kind == RT_KIND_SPHERE) {
                 const rt_sphere& s = sd.spheres[p.index];
-                ls.push_back(LeafSphere{{s.center[0], s.center[1], s.center[2]}, s.radius, prim, k});
+                ls.push_back(LeafSphere{{s.center[0], s.center[1], s.center[2]}, s.radius, prim, k, 0, 0});
             } else if (p.kind == RT_KIND_CONE) {
                 cone_items.push_back(make_uint4(prim, k, p.index, 0));
             } else {
-                poly_items.push_back(make_uint4(prim, k, sd.polygons[p.index].first_vertex, sd.polygons[p.index].vertex_count));
+                const rt_polygon& pg = sd.polygons[p.index];
+                LeafSphere e{{0.0f, 0.0f, 0.0f}, 0.0f, prim, k, pg.first_vertex, pg.vertex_count};
+                poly_bounds = poly_bounds && polygon_bound(sd.vertices.data(), pg.first_vertex, pg.vertex_count, e.c, &e.r);
+                lp.push_back(e);
             }
         }
+        // polygon runs worth a hierarchy get one over the spheres that stand in for the polygons
+        uint32_t pu0 = 0xffffffffu;
+        if (poly_bounds && lp.size() >= 12) {
+            pu0 = cluster_spheres(lp, bnd);
+            any_poly_walk = true;
+        }
+        for (const LeafSphere& e : lp) poly_items.push_back(make_uint4(e.prim, e.pos, e.a0, e.a1));
         const uint32_t u0 = cluster_spheres(ls, bnd);  // re-ordered, padded to 8, bounding records appended
         const uint32_t ns = (uint32_t)ls.size();
         for (const LeafSphere& e : ls) {
@@ -244,7 +256,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             sph_id.push_back(make_uint2(e.prim, e.pos));
         }
         nodes[ni * 4 + 2] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
-        nodes[ni * 4 + 3] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, 0);
+        nodes[ni * 4 + 3] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, pu0);
     }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;
@@ -297,6 +309,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.lights = sc->lights.p;
     d.n_lights = (uint32_t)sd.lights.size();
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
+    d.lean = (cone_items.empty() && !any_poly_walk) ? 1u : 0u;
     memcpy(d.bg, sd.background, sizeof(d.bg));
     // the per-lane traversal stack lives in LDS: depth * 8 B * RT_BLOCK lanes per block
     if ((size_t)d.stack_depth * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t) > 160 * 1024)

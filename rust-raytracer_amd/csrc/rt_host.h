@@ -18,16 +18,21 @@ struct HostTree {
 int prim_box(const rt_scene_desc& d, uint32_t prim, float corner[3], float extent[3]);
 int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err);
 
-// leaf_cluster.cpp: bounding-sphere groups over the spheres of one leaf
-struct LeafSphere {
+// leaf_cluster.cpp: bounding-sphere groups over one kind of primitive of one leaf
+struct LeafSphere {      // a sphere, or the sphere that stands in for a polygon (polygon_bound)
     float c[3];
     float r;
     uint32_t prim, pos;  // primitive id, position in the leaf's list
+    uint32_t a0, a1;     // polygons: first vertex, vertex count
 };
-// Re-orders `v` by size and position, pads it to a multiple of 8 entries (padding = copies of
-// entries with bit 31 of `pos` set), and appends the leaf's block of bounding records to `bnd`
-// (4 floats each); returns the index of the block's header record.
+// Re-orders `v` spatially, pads it to a multiple of 8 entries (padding = copies of entries with
+// bit 31 of `pos` set), and appends the run's block of bounding records to `bnd` (4 floats each);
+// returns the index of the block's header record.
 uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd);
+// Sphere {c, r} such that whenever Polygon::intersect (reference src/polygon.rs:58-293) accepts
+// a ray, the ray's line passes within r + 1.1e-5 |src - c| of c.  False if no such bound exists
+// (coordinates that are not finite).
+bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, float c[3], float* r);
 
 // Validates counts, pointers and every index in a scene description.
 int validate_desc(const rt_scene_desc& d, std::string& err);

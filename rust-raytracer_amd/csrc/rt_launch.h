@@ -13,7 +13,7 @@ namespace rtamd {
 // Scene as the kernels see it (all device pointers).
 struct DevScene {
     // 4 x uint4 per node (64 B): {bmin, plane} {bmax, axis}; interior: {under, over, -, -} {-};
-    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, header of the sphere run's bounding records, -}
+    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, header of the sphere run's bounding records, same of the polygon run or ~0}
     const uint4* nodes;
     // Leaf primitive lists, one run per kind and leaf, each in the builder's list order.
     const float4* sph;         // sphere runs: {centre, r*r}; every run padded to a multiple of 8 entries
@@ -29,6 +29,7 @@ struct DevScene {
     const float4* lights;      // 2 per light: {position, 0} {color, 0}
     uint32_t n_lights;
     uint32_t stack_depth;      // entries per lane in the traversal stack (>= tree depth, >= 1)
+    uint32_t lean;             // 1: no cones and no polygon run with bounding records anywhere in the scene
     float bg[3];
 };
 

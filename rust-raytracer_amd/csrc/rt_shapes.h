@@ -29,6 +29,9 @@
 #endif
 
 #define RT_DEV __device__ __forceinline__
+// The two big shape routines are called, not inlined: every copy costs kilobytes of code, and the
+// intersect and shadow kernels that run side by side must share the 64 KiB instruction cache.
+#define RT_DEV_CALL __device__ __noinline__
 
 namespace RT_NS {
 
@@ -264,7 +267,7 @@ RT_DEV F3 sphere_normal(F3 c, F3 src, F3 ray, float t) { return normalized(sub(a
 // ---------------------------------------------------------------------------------------
 // Cone / cylinder / frustum without caps, src/cone.rs:97-221
 // ---------------------------------------------------------------------------------------
-RT_DEV bool isect_cone(F3 base, float br, F3 apex, float ar, F3 src, F3 ray, float near, float& t_out, F3& n_out) {
+RT_DEV_CALL bool isect_cone(F3 base, float br, F3 apex, float ar, F3 src, F3 ray, float near, float& t_out, F3& n_out) {
     F3 base_to_apex = sub(apex, base);
     F3 w = normalized(base_to_apex);
     F3 e;
@@ -316,7 +319,7 @@ RT_DEV bool isect_cone(F3 base, float br, F3 apex, float ar, F3 src, F3 ray, flo
 // vpos / vnrm hold one float4 per vertex.
 // ---------------------------------------------------------------------------------------
 template <class Ctr>
-RT_DEV bool isect_polygon(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
+RT_DEV_CALL bool isect_polygon(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
                           F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
     const F3 v0 = from4(vpos[first]);
     const F3 v1 = from4(vpos[first + 1]);

@@ -194,7 +194,7 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
                           uint32_t ignore, LeafBest& lb, Ctr& ctr) {
     for (uint32_t k = 0; k < count; ++k) {
         const uint4 it = ld_u4<U>(S.poly_items, first + k);  // {prim, list position, first vertex, n vertices}
-        if (it.x == ignore) continue;
+        if (it.x == ignore || (it.y >> 31) != 0u) continue;  // (bit 31: a padding copy of another entry)
         ctr.poly_tests(1);
         float t;
         F3 n;
@@ -302,9 +302,29 @@ RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, fl
     }
 }
 
-template <bool BEHIND, class Ctr>
-RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, float a,
-                              float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
+// The 8 polygons of items i0 .. i0+7 (padding copies skipped).
+template <class Ctr>
+RT_DEV void polygons8(const DevScene& S, uint32_t i0, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint4 it = S.poly_items[i0 + k];
+        if (it.x == ignore || (it.y >> 31) != 0u) continue;
+        ctr.poly_tests(1);
+        float t;
+        F3 n;
+        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, src, ray, near, t, n, ctr)) {
+            ctr.poly_hits(1);
+            if (lb.better(t, it.y)) {
+                lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
+            }
+        }
+    }
+}
+
+// POLY: the run holds polygons, each bounded by the sphere polygon_bound (leaf_cluster.cpp)
+// derives for it; the records and their test are the same.
+template <bool POLY, bool BEHIND, class Ctr>
+RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, float a,
+                          float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
     const float4 hf = S.bnd[header];
     ctr.bound_tests(1);
     const bool fwd = near >= 0.0f;
@@ -327,7 +347,8 @@ RT_DEV void leaf_spheres_lane(const DevScene& S, uint32_t first, uint32_t count,
             }
             const uint32_t k = (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
-            cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
+            if constexpr (POLY) polygons8(S, first + (g * 8u + k) * 8u, src, ray, near, ignore, lb, ctr);
+            else cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
         }
     };
 
@@ -402,9 +423,11 @@ RT_DEV bool unwind(const uint2* my_stack, uint32_t stride, uint32_t& sp, F3 src,
     return false;
 }
 
-// CULL: 0 = every entry of every visited leaf, 1 = big sphere runs skip groups the ray's line
-// misses, 2 = also groups behind the ray's origin (worth its cost for rays that start inside
-// the scene).
+// CULL: 0 = every entry of every visited leaf, 1 = big runs skip groups the ray's line misses,
+// 2 = also groups behind the ray's origin (worth its cost for rays that start inside the
+// scene); + 4 = the scene has neither cones nor polygon runs with bounding records, and the
+// kernel carries no code for them (kilobytes less for the instruction cache, which the
+// intersect and shadow kernels of a frame share).
 template <int CULL, class Ctr>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr) {
@@ -416,6 +439,10 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     const uint32_t stride = blockDim.x;
     uint2* my_stack = stack + threadIdx.x;
     uint32_t* lane_words = (uint32_t*)(stack + S.stack_depth * stride) + threadIdx.x;  // RT_LANE_WORDS per lane, same stride
+    // the bounding-record test assumes that its intermediate values stay finite
+    const bool tame = a > 0.0f && a < 1e16f && dot(src, src) < 1e16f;
+    constexpr int MODE = CULL & 3;
+    constexpr bool LEAN = (CULL & 4) != 0;
     uint32_t sp = 0;
     uint32_t cur = 0;
     bool done = false;
@@ -456,14 +483,25 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
         if (at_leaf) {
             LeafBest lb;
             lb.init();
-            if constexpr (CULL != 0) {
+            if constexpr (MODE != 0) {
                 if (q2.y >= CULL_MIN_SPHERES) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_spheres_lane<CULL == 2>(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                    leaf_run_lane<false, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
                     q2.y = 0u;
                 }
+                if constexpr (!LEAN) {
+                    if (q3.w != 0xffffffffu && tame) {  // polygon run with bounding records
+                        leaf_run_lane<true, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                        q3.y = 0u;
+                    }
+                }
             }
-            if (q2.y + q2.w + q3.y >= BIG_LEAF) {
-                // all lanes standing on the same leaf walk it together, index wave-uniform
+            // What is left (short runs, cones, rays the bounding test cannot take): entry by entry.
+            // Long lists are walked by all lanes standing on the same leaf together, index
+            // wave-uniform (entries arrive by scalar loads); the culling kernels only keep that
+            // path for cones, the one kind without bounding records.
+            if constexpr (LEAN) q2.w = 0u;  // (there are no cones)
+            const uint32_t together = MODE != 0 ? q2.w : q2.y + q2.w + q3.y;
+            if (together >= BIG_LEAF) {
                 bool mine_done = false;
                 while (!mine_done) {
                     if (cur == (uint32_t)__builtin_amdgcn_readfirstlane(cur)) {
@@ -472,9 +510,14 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                                                     __builtin_amdgcn_readfirstlane(q2.z), __builtin_amdgcn_readfirstlane(q2.w));
                         const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y),
                                                     0u, 0u);
-                        leaf_runs<true>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
+                        if constexpr (MODE != 0) leaf_cones<true>(S, u2.z, u2.w, src, ray, near, ignore, lb, ctr);
+                        else leaf_runs<true>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
                         mine_done = true;
                     }
+                }
+                if constexpr (MODE != 0) {
+                    q2.w = 0u;
+                    leaf_runs<false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
                 }
             } else {
                 leaf_runs<false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);

@@ -124,3 +124,86 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
     hit = wp != 0xFFFFFFFF
     assert 0.2 < (hit & (wp != 0)).mean() < 0.98  # both sphere hits and misses are exercised
+
+
+def polygon_cloud(rng, n, scale, offset):
+    """A floor (which keeps the reference's builder from splitting) over a cloud of triangles
+    and quads: ordinary ones, slivers whose first three vertices are nearly collinear (their
+    plane normal is rounding noise), axis-aligned ones, and non-planar quads."""
+    lines = ["v", "from %g %g %g" % tuple(offset + scale * np.array([3.0, 3.0, 2.0])), "at %g %g %g" % tuple(offset),
+             "up 0 0 1", "angle 40", "hither %g" % (scale * 1e-3), "resolution 32 32", "l %g %g %g" % tuple(offset + 5 * scale),
+             "f 1 0.5 0.5 0.5 0.5 3 0 0", "p 4"]
+    for sx, sy in ((-30, -30), (30, -30), (30, 30), (-30, 30)):
+        lines.append("%.9g %.9g %.9g" % (offset[0] + sx * scale, offset[1] + sy * scale, offset[2] - 1.5 * scale))
+    polys = []
+    for k in range(n):
+        c = offset + rng.uniform(-1, 1, 3) * scale
+        size = scale * 10.0 ** rng.uniform(-2.5, -0.7)
+        kind = k % 5
+        nv = 4 if kind == 4 else 3
+        v = c + rng.normal(size=(nv, 3)) * size
+        if kind == 1:    # sliver: the third vertex almost on the line through the first two
+            v[2] = v[0] + (v[1] - v[0]) * rng.uniform(0.2, 0.8) + rng.normal(size=3) * size * 1e-6
+        elif kind == 2:  # axis-aligned
+            v[:, rng.integers(0, 3)] = c[rng.integers(0, 3)]
+        v = v.astype(np.float32)
+        polys.append(v)
+        lines.append("p %d" % nv)
+        for p in v:
+            lines.append("%.9g %.9g %.9g" % tuple(p))
+    return "\n".join(lines) + "\n", polys
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, (0.0, 0.0, 0.0)), (1.0, (1000.0, 1000.0, 500.0)), (1e-3, (0.5, 0.25, -0.125))])
+def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset):
+    """Big polygon leaves skip groups of polygons through the spheres that stand in for them.
+    Same bar as for spheres: primitive, distance bits and normal bits of the culled walk equal the
+    exhaustive walk and the oracle, for rays through vertices and along edges (to a few ulps),
+    rays almost inside a polygon's plane, origins on polygons and far away, unnormalised rays."""
+    rng = np.random.default_rng(13)
+    offset = np.array(offset, np.float64)
+    text, polys = polygon_cloud(rng, 3001, scale, offset)
+    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    o = oracle.OracleScene(text, build_threads=4)
+    assert o.info.max_leaf > 1000
+    n = 40000
+    pick = rng.integers(0, len(polys), n)
+    tgt = np.zeros((n, 3))
+    inplane = np.zeros((n, 3))
+    for i, k in enumerate(pick):
+        v = polys[k].astype(np.float64)
+        mode = i % 4
+        w = rng.dirichlet(np.ones(len(v)))
+        if mode == 1:    # a vertex
+            w = np.eye(len(v))[rng.integers(0, len(v))]
+        elif mode == 2:  # a point of an edge
+            j = rng.integers(0, len(v))
+            w = np.zeros(len(v)); t = rng.random(); w[j] = t; w[(j + 1) % len(v)] = 1 - t
+        tgt[i] = w @ v * (1.0 + rng.choice([0.0, 1e-7, -1e-7]))
+        inplane[i] = v[1] - v[0]
+    far = rng.choice([0.3, 1.5, 4.0, 60.0, 3000.0], n)[:, None]
+    src = offset + rng.normal(size=(n, 3)) * scale * far
+    graze = rng.random(n) < 0.15  # origins almost in the polygon's plane
+    src = np.where(graze[:, None], tgt + inplane * rng.uniform(2, 50, (n, 1)) + rng.normal(size=(n, 3)) * scale * 1e-5, src)
+    start = rng.integers(0, len(polys), n)
+    on = rng.random(n) < 0.2      # origins on another polygon (as reflection and shadow rays have)
+    src = np.where(on[:, None], np.stack([polys[k].astype(np.float64).mean(0) for k in start]), src)
+    d = tgt - src
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-300)
+    d *= rng.choice([1.0, 1.0, 0.01, 250.0], n)[:, None]
+    src, d = src.astype(np.float32), d.astype(np.float32)
+    near = rng.choice(np.array([0.0, 0.0, 1e-4, -0.25], np.float32) * np.float32(scale), n).astype(np.float32)
+    ignore = np.where(rng.random(n) < 0.3, np.where(on, start, pick) + 1, 0xFFFFFFFF).astype(np.uint32)
+    wp, wd, wn = o.intersect_rays(src, d, near, ignore)
+    ep, ed, en = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_EXHAUSTIVE)
+    gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
+    assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
+    assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    hit = wp != 0xFFFFFFFF
+    # (at the 1e-3 scale most polygons fail the reference's |ray . normal| >= 1e-6 test: few hits)
+    assert 0.05 < (hit & (wp != 0)).mean() < 0.98
+    # the fast build's plane normals differ in the last bits; its culling must still agree with
+    # its own exhaustive walk
+    fp, fd, fn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST | rtamd.DEBUG_EXHAUSTIVE)
+    cp, cd, cn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST)
+    assert np.array_equal(cp, fp) and np.array_equal(bits(cd), bits(fd)) and np.array_equal(bits(cn), bits(fn))
