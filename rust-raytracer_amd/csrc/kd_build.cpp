@@ -12,10 +12,10 @@
 // expand_to_fit does (src/shape.rs:59-82).
 //
 // Unlike the reference this is iterative (explicit work stack), evaluates the
-// candidates of one node on several threads (each candidate is independent; the
-// arg-min scan is done in candidate order afterwards), keeps only the cost per
-// candidate and re-derives the winner's boxes, and refuses scenes on which the
-// reference's recursion never ends.
+// candidates of one node on several threads or, for big nodes when a scene is created,
+// on the GPU (each candidate is independent; the arg-min scan is done in candidate order
+// afterwards), keeps only the cost per candidate and re-derives the winner's boxes, and
+// refuses scenes on which the reference's recursion never ends.
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -150,7 +150,7 @@ int prim_box(const rt_scene_desc& d, uint32_t prim, float corner[3], float exten
     return 0;
 }
 
-int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err) {
+int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err, const SplitCostFn* wide_cost, uint32_t wide_min) {
     auto t0 = std::chrono::steady_clock::now();
     out.nodes.clear();
     out.refs.clear();
@@ -219,7 +219,11 @@ int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err) {
                 for (size_t c = c0; c < c1; ++c)
                     cost[c] = appraise_split(w.list, boxes, axis, plane_of(c), nullptr, nullptr, nullptr, nullptr);
             };
-            if (threads > 1 && n >= 256) {
+            static_assert(sizeof(Box) == 6 * sizeof(float), "boxes are handed over as 6 floats");
+            if (wide_cost && n >= wide_min &&
+                (*wide_cost)(&boxes[0].c[0], d.n_primitives, w.list.data(), (uint32_t)n, axis, cost.data())) {
+                // (evaluated on the GPU: rt_kernels.hip k_appraise, the same arithmetic)
+            } else if (threads > 1 && n >= 256) {
                 std::atomic<size_t> next{0};
                 std::vector<std::thread> pool;
                 for (int t = 0; t < threads; ++t)

@@ -202,8 +202,36 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     } else {
         rt_scene_desc d = sc->data.desc;
         d.build_threads = desc->build_threads;
-        rc = build_tree(d, sc->tree, err);
+        // Nodes with many primitives have their candidate planes costed on the GPU (2n candidates
+        // x n primitives each: the O(n^2) part of the reference's construction).
+        DevBuf<float> d_boxes, d_cost;
+        DevBuf<uint32_t> d_list;
+        std::string dev_err;
+        const SplitCostFn on_gpu = [&](const float* boxes6, uint32_t n_prims, const uint32_t* list, uint32_t n, int axis,
+                                       float* cost) -> bool {
+            if (!dev_err.empty()) return false;
+            hipError_t e = hipSuccess;
+            if (!d_boxes.p) {
+                e = d_boxes.alloc((size_t)n_prims * 6);
+                if (e == hipSuccess) e = hipMemcpy(d_boxes.p, boxes6, (size_t)n_prims * 6 * sizeof(float), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = d_list.alloc(n_prims);  // a node's list never exceeds the scene (:160-169)
+                if (e == hipSuccess) e = d_cost.alloc((size_t)n_prims * 2);
+            }
+            if (e == hipSuccess && n > n_prims) return false;
+            if (e == hipSuccess) e = hipMemcpy(d_list.p, list, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = rt_exact::launch_appraise(d_boxes.p, d_list.p, n, (uint32_t)axis, d_cost.p, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(cost, d_cost.p, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                dev_err = hipGetErrorString(e);
+                return false;  // the host threads take over
+            }
+            return true;
+        };
+        const char* wm = getenv("RTAMD_GPU_BUILD_MIN");  // primitives in a node from which the GPU costs it
+        const uint32_t wide_min = wm ? (uint32_t)strtoul(wm, nullptr, 10) : 2048u;
+        rc = build_tree(d, sc->tree, err, &on_gpu, wide_min);
         if (rc != RT_OK) return fail(ctx, rc, err);
+        if (!dev_err.empty()) return fail(ctx, RT_ERR_DEVICE, "tree construction on the GPU: " + dev_err);
     }
 
     const SceneData& sd = sc->data;

@@ -1,6 +1,7 @@
 // Internal host-side declarations shared by the translation units of librtamd.so.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -16,7 +17,12 @@ struct HostTree {
 
 // kd_build.cpp
 int prim_box(const rt_scene_desc& d, uint32_t prim, float corner[3], float extent[3]);
-int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err);
+// Costs of all 2n candidate planes of one node (candidate 2k = min, 2k+1 = max of the k-th listed
+// primitive's box on `axis`), evaluated somewhere faster than the host threads; boxes6 holds
+// {corner, extent} per primitive of the scene.  Returns false if it cannot take the node.
+using SplitCostFn = std::function<bool(const float* boxes6, uint32_t n_prims, const uint32_t* list, uint32_t n, int axis, float* cost)>;
+int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err, const SplitCostFn* wide_cost = nullptr,
+               uint32_t wide_min = 0);
 
 // leaf_cluster.cpp: bounding-sphere groups over one kind of primitive of one leaf
 struct LeafSphere {      // a sphere, or the sphere that stands in for a polygon (polygon_bound)

@@ -380,6 +380,62 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(FrameArgs A, uint32_t leve
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Tree construction: cost of every candidate plane of one node, one thread per candidate
+// (appraise_split + appraise, reference src/space_partition.rs:100-149, :184-193).  A candidate's
+// two boxes grow over the node's primitives in list order with BoundingBox::expand_to_fit's
+// arithmetic (src/shape.rs:59-82), so the costs are the host builder's, bit for bit; every
+// thread reads the same primitive at the same time (scalar loads).  Only the build without
+// contraction (rt_exact) is used.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK) k_appraise(const float* __restrict__ boxes6, const uint32_t* __restrict__ list,
+                                                       uint32_t n, uint32_t axis, float* __restrict__ cost) {
+    const uint32_t c = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t cc = c < 2u * n ? c : 0u;
+    const float* mine = boxes6 + (size_t)list[cc >> 1] * 6u;
+    const float plane = (cc & 1u) ? mine[axis] + mine[3 + axis] : mine[axis];  // src/shape.rs:37-39
+    float uc[3] = {0, 0, 0}, ue[3] = {0, 0, 0}, oc[3] = {0, 0, 0}, oe[3] = {0, 0, 0};
+    uint32_t nu = 0, no = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* b = boxes6 + (size_t)list[i] * 6u;
+        const float bc[3] = {b[0], b[1], b[2]}, be[3] = {b[3], b[4], b[5]};
+        const float b_min = b[axis], b_ext = b[3 + axis];  // (read again rather than indexing registers)
+        if (b_min < plane) {
+            if (nu == 0) {
+                for (int a = 0; a < 3; ++a) { uc[a] = bc[a]; ue[a] = be[a]; }
+            } else {
+                for (int a = 0; a < 3; ++a) {
+                    const float mn = fminf(uc[a], bc[a]);
+                    const float mx = fmaxf(uc[a] + ue[a], bc[a] + be[a]);
+                    uc[a] = mn;
+                    ue[a] = mx - mn;
+                }
+            }
+            ++nu;
+        }
+        if (b_min + b_ext >= plane) {
+            if (no == 0) {
+                for (int a = 0; a < 3; ++a) { oc[a] = bc[a]; oe[a] = be[a]; }
+            } else {
+                for (int a = 0; a < 3; ++a) {
+                    const float mn = fminf(oc[a], bc[a]);
+                    const float mx = fmaxf(oc[a] + oe[a], bc[a] + be[a]);
+                    oc[a] = mn;
+                    oe[a] = mx - mn;
+                }
+            }
+            ++no;
+        }
+    }
+    const float sa_u = ue[0] * ue[1] * 2.0f + ue[1] * ue[2] * 2.0f + ue[0] * ue[2] * 2.0f;  // src/shape.rs:45-49
+    const float sa_o = oe[0] * oe[1] * 2.0f + oe[1] * oe[2] * 2.0f + oe[0] * oe[2] * 2.0f;
+    float r = 0.0f;
+    if (nu > 0 && no > 0) r = sa_u * (float)nu + sa_o * (float)no;
+    else if (nu > 0) r = sa_u * (float)nu;
+    else if (no > 0) r = sa_o * (float)no;
+    if (c < 2u * n) cost[c] = r;
+}
+
 // Gathered compact tile buffers -> row-major image.  One thread per pixel.
 __global__ void __launch_bounds__(RT_BLOCK) k_deinterleave(DeinterleaveArgs D) {
     const uint64_t p = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -575,6 +631,11 @@ hipError_t launch_light(const FrameArgs& A, uint32_t first_level, uint32_t last_
 hipError_t launch_resolve(const FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st) {
     if (level == 0) hipLaunchKernelGGL((k_resolve<true>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
     else hipLaunchKernelGGL((k_resolve<false>), dim3(grid), dim3(RT_BLOCK), 0, st, A, level);
+    return hipGetLastError();
+}
+
+hipError_t launch_appraise(const float* boxes6, const uint32_t* list, uint32_t n, uint32_t axis, float* cost, hipStream_t st) {
+    hipLaunchKernelGGL(k_appraise, dim3((2u * n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, boxes6, list, n, axis, cost);
     return hipGetLastError();
 }
 

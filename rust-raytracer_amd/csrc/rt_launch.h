@@ -88,6 +88,8 @@ struct DeinterleaveArgs {
     hipError_t launch_light(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work,         \
                             uint32_t grid, hipStream_t st);                                                          \
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \
+    hipError_t launch_appraise(const float* boxes6, const uint32_t* list, uint32_t n, uint32_t axis, float* cost,    \
+                               hipStream_t st);                                                                      \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
     hipError_t launch_debug_intersect(const rtamd::DevScene& S, bool cull, uint64_t n, const float* src, const float* ray, \
                                       const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist, \
