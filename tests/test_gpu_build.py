@@ -34,6 +34,9 @@ def test_big_scene_builds_fast(rtamd, spd, gpu_ctx):
     sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
     dt = time.perf_counter() - t0
     assert sc.tree_info.n_nodes > 100
+    info, nodes, refs = sc.parsed.build_tree(threads=8)  # the same tree as the host threads build
+    gn, gr = sc.tree()
+    assert gn.tobytes() == nodes.tobytes() and np.array_equal(gr, refs)
     print("mount size 7: scene created in %.2f s, tree %.0f ms" % (dt, sc.tree_info.build_ms))
     _, u8, st = sc.render(rtamd.RenderOptions(max_depth=2), 64, 64, want_f32=False)
     assert st.rays_primary == 64 * 64
