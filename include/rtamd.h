@@ -189,6 +189,19 @@ int rt_render(rt_context* ctx, const rt_scene* scene, const rt_view* view, const
 int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                      void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out);
 
+/* The same frame in two steps, for callers that render frame after frame (no counterpart in the
+ * reference, which renders one image and exits).  rt_render_device_begin puts the frame on the
+ * GPU and returns at once; rt_render_device_end waits for it, re-runs it with larger ray pools
+ * if they overflowed, and fills the statistics.  At most two frames may be in flight: the
+ * small launches that end one frame then run beside the big launches that start the next.
+ * Only the frame's last kernel touches the output buffers, and it is ordered after everything
+ * `stream` held when begin was called; `stream` in turn waits for the frame, so work queued on
+ * it afterwards (a copy, a gather) sees the finished image.  Tickets are 0 and 1; a ticket is
+ * free again once rt_render_device_end has returned. */
+int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                           void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out);
+int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out);
+
 /* ---- interleaved 8x8 tiles over ranks (pure index math + one device kernel) ---- */
 
 /* Number of pixel slots in the compact tile buffer of `rank` (64 per tile, edge tiles padded). */

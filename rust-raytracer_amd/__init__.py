@@ -36,7 +36,7 @@ OP_AABB, OP_SPHERE, OP_CONE, OP_POLYGON, OP_PHONG, OP_BLINN, OP_REFLECT, OP_REFR
 # every symbol include/rtamd.h declares
 EXPORTED_SYMBOLS = (
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_scene_create", "rt_scene_destroy",
-    "rt_scene_tree_info", "rt_scene_tree_copy", "rt_render", "rt_render_device", "rt_tile_pixels",
+    "rt_scene_tree_info", "rt_scene_tree_copy", "rt_render", "rt_render_device", "rt_render_device_begin", "rt_render_device_end", "rt_tile_pixels",
     "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
@@ -170,6 +170,9 @@ def lib():
     L.rt_scene_tree_copy.argtypes = [vp, vp, vp]
     L.rt_render.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, C.POINTER(rt_stats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, vp, C.POINTER(rt_stats)]
+    L.rt_render_device_begin.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, vp,
+                                         C.POINTER(C.c_uint32)]
+    L.rt_render_device_end.argtypes = [vp, C.c_uint32, C.POINTER(rt_stats)]
     for f in (L.rt_tile_pixels, L.rt_tile_pixels_max, L.rt_tile_slot):
         f.restype = C.c_uint64
     L.rt_tile_pixels.argtypes = [C.c_uint32] * 4
@@ -229,7 +232,7 @@ class ParsedScene:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # (module globals are gone when the interpreter shuts down)
             lib().rt_parsed_free(h)
             self._h = None
 
@@ -308,7 +311,7 @@ class Context:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # (module globals are gone when the interpreter shuts down)
             lib().rt_context_destroy(h)
             self._h = None
 
@@ -363,7 +366,7 @@ class Scene:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # (module globals are gone when the interpreter shuts down)
             lib().rt_scene_destroy(h)
             self._h = None
 
@@ -407,6 +410,21 @@ class Scene:
         o = opt.c()
         self.ctx.check(lib().rt_render_device(self.ctx._h, self._h, C.byref(v), C.byref(o), d_f32, d_u8, stream,
                                               C.byref(st)))
+        return st
+
+    def render_device_begin(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0):
+        """Puts the frame on the GPU and returns a ticket at once (at most two in flight)."""
+        v = self.view(width, height)
+        o = opt.c()
+        ticket = C.c_uint32()
+        self.ctx.check(lib().rt_render_device_begin(self.ctx._h, self._h, C.byref(v), C.byref(o), d_f32, d_u8, stream,
+                                                    C.byref(ticket)))
+        return ticket.value
+
+    def render_device_end(self, ticket):
+        """Waits for the frame of `ticket`; returns its rt_stats."""
+        st = rt_stats()
+        self.ctx.check(lib().rt_render_device_end(self.ctx._h, ticket, C.byref(st)))
         return st
 
     def debug_intersect(self, src, ray, near, ignore, fp_mode=FP_EXACT):

@@ -47,10 +47,10 @@ struct DevBuf {
 
 }  // namespace
 
-struct rt_context {
-    int device = 0;
-    std::string err;
-    // frame workspace, kept across calls and grown on demand
+// Everything one frame in flight owns.  A context has two, so that the small, latency-bound
+// launches at the end of one frame can run beside the big first launches of the next.
+struct FrameSlot {
+    // workspace, kept across frames and grown on demand
     DevBuf<float4> ray_o, ray_d, node_col, hit_a, sray_o, sray_d;
     DevBuf<uint32_t> hit_p, sray_blocked;
     DevBuf<uint2> node_sh;
@@ -60,12 +60,29 @@ struct rt_context {
     DevBuf<uint32_t> levels;
     DevBuf<unsigned long long> counters;
     size_t pool_cap = 0;
+    hipStream_t main_stream = nullptr;    // the frame's kernels
+    hipStream_t shadow_stream = nullptr;  // shadow rays of a level run here, beside the next levels
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // timing: start, traced, resolved
+    hipEvent_t ev_level[RT_MAX_LEVELS] = {};         // level l intersected and spawned
+    hipEvent_t ev_shadow = nullptr;                  // all shadow launches done
+    hipEvent_t ev_caller = nullptr;                  // what the caller's stream held when the frame began
+    // the frame in flight
+    bool busy = false;
+    const rt_scene* scene = nullptr;
+    rt_view view{};
+    rt_options opt{};
+    void* out_f32 = nullptr;
+    void* out_u8 = nullptr;
+    hipStream_t caller = nullptr;
+};
+
+struct rt_context {
+    int device = 0;
+    std::string err;
+    FrameSlot slot[2];
+    uint32_t next_slot = 0;
     DevBuf<float> out_f32;
     DevBuf<uint8_t> out_u8;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    hipStream_t shadow_stream = nullptr;  // shadow rays of a level run here, beside the next levels
-    hipEvent_t ev_level[RT_MAX_LEVELS] = {};  // level l intersected and spawned
-    hipEvent_t ev_shadow = nullptr;           // all shadow launches done
     bool kernels_ready = false;
 };
 
@@ -106,25 +123,25 @@ float bits_to_float(uint32_t u) {
     return f;
 }
 
-int ensure_pool(rt_context* ctx, size_t cap) {
-    if (ctx->pool_cap >= cap) return RT_OK;
-    RT_HIP(ctx, ctx->ray_o.alloc(cap));
-    RT_HIP(ctx, ctx->ray_d.alloc(cap));
-    RT_HIP(ctx, ctx->node_col.alloc(cap));
-    RT_HIP(ctx, ctx->node_kid.alloc(cap));
-    RT_HIP(ctx, ctx->hit_a.alloc(cap));
-    RT_HIP(ctx, ctx->hit_p.alloc(cap));
-    RT_HIP(ctx, ctx->node_sh.alloc(cap));
-    ctx->pool_cap = cap;
+int ensure_pool(rt_context* ctx, FrameSlot& f, size_t cap) {
+    if (f.pool_cap >= cap) return RT_OK;
+    RT_HIP(ctx, f.ray_o.alloc(cap));
+    RT_HIP(ctx, f.ray_d.alloc(cap));
+    RT_HIP(ctx, f.node_col.alloc(cap));
+    RT_HIP(ctx, f.node_kid.alloc(cap));
+    RT_HIP(ctx, f.hit_a.alloc(cap));
+    RT_HIP(ctx, f.hit_p.alloc(cap));
+    RT_HIP(ctx, f.node_sh.alloc(cap));
+    f.pool_cap = cap;
     return RT_OK;
 }
 
-int ensure_shadow(rt_context* ctx, size_t cap) {
-    if (ctx->shadow_cap >= cap) return RT_OK;
-    RT_HIP(ctx, ctx->sray_o.alloc(cap));
-    RT_HIP(ctx, ctx->sray_d.alloc(cap));
-    RT_HIP(ctx, ctx->sray_blocked.alloc(cap));
-    ctx->shadow_cap = cap;
+int ensure_shadow(rt_context* ctx, FrameSlot& f, size_t cap) {
+    if (f.shadow_cap >= cap) return RT_OK;
+    RT_HIP(ctx, f.sray_o.alloc(cap));
+    RT_HIP(ctx, f.sray_d.alloc(cap));
+    RT_HIP(ctx, f.sray_blocked.alloc(cap));
+    f.shadow_cap = cap;
     return RT_OK;
 }
 
@@ -148,23 +165,32 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
     RT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, RT_ERR_UNSUPPORTED, std::string("librtamd is built for gfx950 only; device is ") + prop.gcnArchName);
-    for (auto& e : ctx->ev) RT_HIP(ctx, hipEventCreate(&e));
-    RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->shadow_stream, hipStreamNonBlocking));
-    for (auto& e : ctx->ev_level) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_shadow, hipEventDisableTiming));
-    RT_HIP(ctx, ctx->levels.alloc(LV_WORDS));
-    RT_HIP(ctx, ctx->counters.alloc(20));
+    for (FrameSlot& f : ctx->slot) {
+        for (auto& e : f.ev) RT_HIP(ctx, hipEventCreate(&e));
+        RT_HIP(ctx, hipStreamCreateWithFlags(&f.main_stream, hipStreamNonBlocking));
+        RT_HIP(ctx, hipStreamCreateWithFlags(&f.shadow_stream, hipStreamNonBlocking));
+        for (auto& e : f.ev_level) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_shadow, hipEventDisableTiming));
+        RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_caller, hipEventDisableTiming));
+        RT_HIP(ctx, f.levels.alloc(LV_WORDS));
+        RT_HIP(ctx, f.counters.alloc(20));
+    }
     return RT_OK;
 }
 
 extern "C" void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
-    for (auto& e : ctx->ev)
-        if (e) (void)hipEventDestroy(e);
-    for (auto& e : ctx->ev_level)
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->ev_shadow) (void)hipEventDestroy(ctx->ev_shadow);
-    if (ctx->shadow_stream) (void)hipStreamDestroy(ctx->shadow_stream);
+    for (FrameSlot& f : ctx->slot) {
+        if (f.busy && f.main_stream) (void)hipStreamSynchronize(f.main_stream);
+        for (auto& e : f.ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : f.ev_level)
+            if (e) (void)hipEventDestroy(e);
+        if (f.ev_shadow) (void)hipEventDestroy(f.ev_shadow);
+        if (f.ev_caller) (void)hipEventDestroy(f.ev_caller);
+        if (f.shadow_stream) (void)hipStreamDestroy(f.shadow_stream);
+        if (f.main_stream) (void)hipStreamDestroy(f.main_stream);
+    }
     delete ctx;
 }
 
@@ -373,25 +399,56 @@ int prepare_kernels(rt_context* ctx) {
 
 }  // namespace
 
-extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
-                                void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {
-    if (!ctx || !scene || !view || !opt) return fail(ctx, RT_ERR_INVALID, "null argument");
-    if (scene->ctx != ctx) return fail(ctx, RT_ERR_INVALID, "scene belongs to another context");
-    if (view->width == 0 || view->height == 0) return fail(ctx, RT_ERR_INVALID, "empty view");
-    if ((uint64_t)view->width * view->height > 0x7fffffffull / 3) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large");
-    if (opt->max_depth + 2 > RT_MAX_LEVELS) return fail(ctx, RT_ERR_UNSUPPORTED, "max_depth too large");
-    if (opt->fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown fp_mode");
-    const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
-    if (opt->tile_rank >= tile_count) return fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_count");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = prepare_kernels(ctx);
-    if (rc != RT_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
+namespace {
 
-    const TileGrid grid(view->width, view->height, tile_count);
-    const uint64_t n_slots64 = grid.tiles_of(opt->tile_rank) * 64;
+struct FramePlan {  // what enqueue and finish both need about a frame
+    uint32_t n_slots = 0, n_lights = 0;
+    uint64_t n_primary = 0;
+    size_t lights1 = 1;
+};
+
+int plan_frame(rt_context* ctx, const FrameSlot& f, FramePlan& p) {
+    const rt_view& view = f.view;
+    const rt_options& opt = f.opt;
+    const uint32_t tile_count = opt.tile_count ? opt.tile_count : 1;
+    const TileGrid grid(view.width, view.height, tile_count);
+    const uint64_t n_slots64 = grid.tiles_of(opt.tile_rank) * 64;
     if (n_slots64 > 0x7fffffffull) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large");
-    const uint32_t n_slots = (uint32_t)n_slots64;
+    p.n_slots = (uint32_t)n_slots64;
+    p.n_lights = f.scene->dev.n_lights;
+    p.lights1 = std::max<uint32_t>(1, p.n_lights);
+    // owned pixels = primary rays
+    if (tile_count == 1) {
+        p.n_primary = (uint64_t)view.width * view.height;
+    } else {
+        p.n_primary = 0;
+        for (uint64_t lt = 0; lt < grid.tiles_of(opt.tile_rank); ++lt) {
+            const uint64_t t = lt * tile_count + opt.tile_rank;
+            const uint32_t tx = (uint32_t)(t % grid.tiles_x), ty = (uint32_t)(t / grid.tiles_x);
+            const uint32_t w = std::min<uint32_t>(8, view.width - tx * 8), h = std::min<uint32_t>(8, view.height - ty * 8);
+            p.n_primary += (uint64_t)w * h;
+        }
+    }
+    return RT_OK;
+}
+
+// Puts the frame of slot `f` on the slot's streams with pools of at least (cap, scap) entries.
+// Nothing here waits for the GPU.  The kernels run on the slot's own stream; only the last one
+// (resolve of level 0, the one that writes the caller's buffers) is ordered after what the
+// caller's stream held when the frame began, and the caller's stream then waits for the frame.
+int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap, size_t scap, bool first_attempt) {
+    const rt_scene* scene = f.scene;
+    const rt_view* view = &f.view;
+    const rt_options* opt = &f.opt;
+    const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
+    const TileGrid grid(view->width, view->height, tile_count);
+    const uint32_t n_slots = p.n_slots, n_lights = p.n_lights;
+    if (cap > 0xfffffff0ull || scap * p.lights1 > 0xfffffff0ull)
+        return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
+    int rc = ensure_pool(ctx, f, cap);
+    if (rc != RT_OK) return rc;
+    rc = ensure_shadow(ctx, f, scap * p.lights1);
+    if (rc != RT_OK) return rc;
 
     FrameArgs A;
     memset(&A, 0, sizeof(A));
@@ -410,135 +467,122 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
     A.n_slots = n_slots;
     A.max_depth = opt->max_depth;
     A.min_contribution = opt->min_contribution;
-    A.out_f32 = (float*)d_rgb_f32_out;
-    A.out_u8 = (uint8_t*)d_rgb_u8_out;
-
-    // owned pixels = primary rays
-    uint64_t n_primary = 0;
-    if (tile_count == 1) {
-        n_primary = (uint64_t)view->width * view->height;
-    } else {
-        for (uint64_t lt = 0; lt < grid.tiles_of(opt->tile_rank); ++lt) {
-            const uint64_t t = lt * tile_count + opt->tile_rank;
-            const uint32_t tx = (uint32_t)(t % grid.tiles_x), ty = (uint32_t)(t / grid.tiles_x);
-            const uint32_t w = std::min<uint32_t>(8, view->width - tx * 8), h = std::min<uint32_t>(8, view->height - ty * 8);
-            n_primary += (uint64_t)w * h;
-        }
-    }
+    A.out_f32 = (float*)f.out_f32;
+    A.out_u8 = (uint8_t*)f.out_u8;
+    A.ray_o = f.ray_o.p;
+    A.ray_d = f.ray_d.p;
+    A.hit_a = f.hit_a.p;
+    A.hit_p = f.hit_p.p;
+    A.node_sh = f.node_sh.p;
+    A.node_col = f.node_col.p;
+    A.node_kid = f.node_kid.p;
+    A.pool_cap = (uint32_t)f.pool_cap;
+    A.sray_o = f.sray_o.p;
+    A.sray_d = f.sray_d.p;
+    A.sray_blocked = f.sray_blocked.p;
+    A.shadow_cap = (uint32_t)(f.shadow_cap / p.lights1);
+    A.level_count = f.levels.p;
+    A.level_base = f.levels.p + RT_MAX_LEVELS;
+    A.shadow_count = f.levels.p + LV_SHADOW_COUNT;
+    A.overflow = f.levels.p + LV_OVERFLOW;
+    A.counters = f.counters.p;
 
     const bool fast = opt->fp_mode == RT_FP_FAST;
     const bool work = opt->collect_work != 0;
     const bool cull = opt->exhaustive_leaves == 0;
-    const uint32_t n_lights = scene->dev.n_lights;
-    if (n_lights > 65535) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 65535 lights");
-    size_t cap = std::max<size_t>(ctx->pool_cap, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
-    // shadow queues hold the whole frame: room for the primary hits and about as many again,
-    // times the number of lights
-    const size_t lights1 = std::max<uint32_t>(1, n_lights);
-    size_t scap = std::max<size_t>(ctx->shadow_cap / lights1, std::max<size_t>((size_t)n_slots * 2, 1u << 16));
+    hipStream_t st = f.main_stream, st2 = f.shadow_stream;
+    if (first_attempt) RT_HIP(ctx, hipEventRecord(f.ev_caller, f.caller));
+    RT_HIP(ctx, hipMemsetAsync(f.levels.p, 0, LV_WORDS * sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(f.counters.p, 0, 20 * sizeof(unsigned long long), st));
+    RT_HIP(ctx, hipEventRecord(f.ev[0], st));
+
+    const uint32_t grid0 = std::max<uint32_t>(1, (n_slots + RT_BLOCK - 1) / RT_BLOCK);
+    // Deeper levels' sizes are only known on the device; launch enough blocks for the
+    // largest plausible level and let blocks past the end exit (grid-stride inside).
+    const uint32_t gridn = std::min<uint32_t>(grid0, 16384);
+    const uint32_t grids = std::min<uint32_t>(grid0, 65535);  // per light: the launch is (grids, n_lights)
+    auto shadow_and_light = [&](uint32_t first, uint32_t last) -> int {
+        const uint32_t gs = first == 0 ? grids : gridn, gl = first == 0 ? grid0 : gridn;
+        RT_HIP(ctx, hipStreamWaitEvent(st2, f.ev_level[last], 0));
+        RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2)
+                         : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
+        RT_HIP(ctx, fast ? rt_fast::launch_light(A, first, last, work, gl, st2)
+                         : rt_exact::launch_light(A, first, last, work, gl, st2));
+        return RT_OK;
+    };
+    for (uint32_t level = 0; level <= opt->max_depth; ++level) {
+        const uint32_t g = level == 0 ? grid0 : gridn;
+        RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
+        if (n_lights) {  // this level's shadow rays and lighting: beside the next levels, on the second stream
+            RT_HIP(ctx, hipEventRecord(f.ev_level[level], st));
+            if (level < SHADOW_GROUP_FROM || level == opt->max_depth) {
+                const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
+                rc = shadow_and_light(first, level);
+                if (rc != RT_OK) return rc;
+            }
+        }
+    }
+    if (n_lights) {
+        RT_HIP(ctx, hipEventRecord(f.ev_shadow, st2));
+        RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_shadow, 0));
+    }
+    RT_HIP(ctx, hipEventRecord(f.ev[1], st));
+    for (uint32_t level = opt->max_depth + 1; level-- > 0;) {
+        const uint32_t g = level == 0 ? grid0 : gridn;
+        if (level == 0) RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_caller, 0));  // the caller's buffers are written from here on
+        RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));
+    }
+    RT_HIP(ctx, hipEventRecord(f.ev[2], st));
+    RT_HIP(ctx, hipStreamWaitEvent(f.caller, f.ev[2], 0));
+    return RT_OK;
+}
+
+// Waits for the frame of slot `f`, grows the pools and runs it again if they overflowed, and
+// fills the statistics.
+int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
+    FramePlan p;
+    int rc = plan_frame(ctx, f, p);
+    if (rc != RT_OK) return rc;
+    const rt_options* opt = &f.opt;
     rt_stats stats;
     memset(&stats, 0, sizeof(stats));
     uint32_t lv[LV_WORDS];
-
     for (uint32_t attempt = 0;; ++attempt) {
-        if (cap > 0xfffffff0ull || scap * lights1 > 0xfffffff0ull)
-            return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
-        rc = ensure_pool(ctx, cap);
-        if (rc != RT_OK) return rc;
-        rc = ensure_shadow(ctx, scap * lights1);
-        if (rc != RT_OK) return rc;
-        A.ray_o = ctx->ray_o.p;
-        A.ray_d = ctx->ray_d.p;
-        A.hit_a = ctx->hit_a.p;
-        A.hit_p = ctx->hit_p.p;
-        A.node_sh = ctx->node_sh.p;
-        A.node_col = ctx->node_col.p;
-        A.node_kid = ctx->node_kid.p;
-        A.pool_cap = (uint32_t)ctx->pool_cap;
-        A.sray_o = ctx->sray_o.p;
-        A.sray_d = ctx->sray_d.p;
-        A.sray_blocked = ctx->sray_blocked.p;
-        A.shadow_cap = (uint32_t)(ctx->shadow_cap / lights1);
-        A.level_count = ctx->levels.p;
-        A.level_base = ctx->levels.p + RT_MAX_LEVELS;
-        A.shadow_count = ctx->levels.p + LV_SHADOW_COUNT;
-        A.overflow = ctx->levels.p + LV_OVERFLOW;
-        A.counters = ctx->counters.p;
-
-        RT_HIP(ctx, hipMemsetAsync(ctx->levels.p, 0, LV_WORDS * sizeof(uint32_t), st));
-        RT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 20 * sizeof(unsigned long long), st));
-        RT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-
-        const uint32_t grid0 = std::max<uint32_t>(1, (n_slots + RT_BLOCK - 1) / RT_BLOCK);
-        // Deeper levels' sizes are only known on the device; launch enough blocks for the
-        // largest plausible level and let blocks past the end exit (grid-stride inside).
-        const uint32_t gridn = std::min<uint32_t>(grid0, 16384);
-        const uint32_t grids = std::min<uint32_t>(grid0, 65535);  // per light: the launch is (grids, n_lights)
-        hipStream_t st2 = ctx->shadow_stream;
-        auto shadow_and_light = [&](uint32_t first, uint32_t last) -> int {
-            const uint32_t gs = first == 0 ? grids : gridn, gl = first == 0 ? grid0 : gridn;
-            RT_HIP(ctx, hipStreamWaitEvent(st2, ctx->ev_level[last], 0));
-            RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2)
-                             : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
-            RT_HIP(ctx, fast ? rt_fast::launch_light(A, first, last, work, gl, st2)
-                             : rt_exact::launch_light(A, first, last, work, gl, st2));
-            return RT_OK;
-        };
-        for (uint32_t level = 0; level <= opt->max_depth; ++level) {
-            const uint32_t g = level == 0 ? grid0 : gridn;
-            RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
-            if (n_lights) {  // this level's shadow rays and lighting: beside the next levels, on the second stream
-                RT_HIP(ctx, hipEventRecord(ctx->ev_level[level], st));
-                if (level < SHADOW_GROUP_FROM || level == opt->max_depth) {
-                    const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
-                    rc = shadow_and_light(first, level);
-                    if (rc != RT_OK) return rc;
-                }
-            }
-        }
-        if (n_lights) {
-            RT_HIP(ctx, hipEventRecord(ctx->ev_shadow, st2));
-            RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_shadow, 0));
-        }
-        RT_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-        for (uint32_t level = opt->max_depth + 1; level-- > 0;) {
-            const uint32_t g = level == 0 ? grid0 : gridn;
-            RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));
-        }
-        RT_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-        RT_HIP(ctx, hipStreamSynchronize(st));
-
-        RT_HIP(ctx, hipMemcpy(lv, ctx->levels.p, sizeof(lv), hipMemcpyDeviceToHost));
+        RT_HIP(ctx, hipEventSynchronize(f.ev[2]));
+        RT_HIP(ctx, hipMemcpy(lv, f.levels.p, sizeof(lv), hipMemcpyDeviceToHost));
         if (lv[LV_OVERFLOW] != 0) {  // a pool overflowed: grow and run the frame again
-            uint64_t need = n_slots;
-            uint64_t sneed = 0;
+            const size_t shadow_cap1 = f.shadow_cap / p.lights1;
+            uint64_t need = p.n_slots, sneed = 0;
             for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed += lv[LV_SHADOW_COUNT + l];
             for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
-            if (need > ctx->pool_cap) cap = std::max<size_t>(ctx->pool_cap * 2, (size_t)need + (need >> 2));
-            if (sneed > A.shadow_cap) scap = std::max<size_t>((size_t)A.shadow_cap * 2, (size_t)sneed + (sneed >> 2));
-            if (need <= ctx->pool_cap && sneed <= A.shadow_cap) { cap = ctx->pool_cap * 2; scap = (size_t)A.shadow_cap * 2; }
+            size_t cap = f.pool_cap, scap = shadow_cap1;
+            if (need > f.pool_cap) cap = std::max<size_t>(f.pool_cap * 2, (size_t)need + (need >> 2));
+            if (sneed > shadow_cap1) scap = std::max<size_t>(shadow_cap1 * 2, (size_t)sneed + (sneed >> 2));
+            if (need <= f.pool_cap && sneed <= shadow_cap1) { cap = f.pool_cap * 2; scap = shadow_cap1 * 2; }
             stats.retries = attempt + 1;
             if (attempt >= 8) return fail(ctx, RT_ERR_CAPACITY, "ray pool still too small after 8 growth steps");
+            rc = enqueue_frame(ctx, f, p, cap, scap, false);
+            if (rc != RT_OK) return rc;
             continue;
         }
         unsigned long long c[20];
-        RT_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
-        stats.rays_primary = n_primary;
+        RT_HIP(ctx, hipMemcpy(c, f.counters.p, sizeof(c), hipMemcpyDeviceToHost));
+        stats.rays_primary = p.n_primary;
         stats.rays_shadow = 0;
-        for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += (uint64_t)lv[LV_SHADOW_COUNT + l] * n_lights;
+        for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += (uint64_t)lv[LV_SHADOW_COUNT + l] * p.n_lights;
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
         for (int k = 0; k < 16; ++k) stats.work[k] = c[4 + k];
-        stats.ray_nodes = n_slots;
+        stats.ray_nodes = p.n_slots;
         stats.levels = 1;
         for (uint32_t l = 1; l <= opt->max_depth; ++l) {
             stats.ray_nodes += lv[l];
             if (lv[l]) stats.levels = l + 1;
         }
         float ms01 = 0, ms12 = 0, ms02 = 0;
-        RT_HIP(ctx, hipEventElapsedTime(&ms01, ctx->ev[0], ctx->ev[1]));
-        RT_HIP(ctx, hipEventElapsedTime(&ms12, ctx->ev[1], ctx->ev[2]));
-        RT_HIP(ctx, hipEventElapsedTime(&ms02, ctx->ev[0], ctx->ev[2]));
+        RT_HIP(ctx, hipEventElapsedTime(&ms01, f.ev[0], f.ev[1]));
+        RT_HIP(ctx, hipEventElapsedTime(&ms12, f.ev[1], f.ev[2]));
+        RT_HIP(ctx, hipEventElapsedTime(&ms02, f.ev[0], f.ev[2]));
         stats.ms_trace = ms01;
         stats.ms_resolve = ms12;
         stats.ms_frame = ms02;
@@ -546,6 +590,64 @@ extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt
     }
     if (stats_out) *stats_out = stats;
     return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                                      void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out) {
+    if (!ctx || !scene || !view || !opt || !ticket_out) return fail(ctx, RT_ERR_INVALID, "null argument");
+    if (scene->ctx != ctx) return fail(ctx, RT_ERR_INVALID, "scene belongs to another context");
+    if (view->width == 0 || view->height == 0) return fail(ctx, RT_ERR_INVALID, "empty view");
+    if ((uint64_t)view->width * view->height > 0x7fffffffull / 3) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large");
+    if (opt->max_depth + 2 > RT_MAX_LEVELS) return fail(ctx, RT_ERR_UNSUPPORTED, "max_depth too large");
+    if (opt->fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown fp_mode");
+    const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
+    if (opt->tile_rank >= tile_count) return fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_count");
+    if (scene->dev.n_lights > 65535) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 65535 lights");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_kernels(ctx);
+    if (rc != RT_OK) return rc;
+    const uint32_t id = ctx->next_slot;
+    FrameSlot& f = ctx->slot[id];
+    if (f.busy) return fail(ctx, RT_ERR_INVALID, "two frames are in flight already: call rt_render_device_end first");
+    f.scene = scene;
+    f.view = *view;
+    f.opt = *opt;
+    f.out_f32 = d_rgb_f32_out;
+    f.out_u8 = d_rgb_u8_out;
+    f.caller = (hipStream_t)stream;
+    FramePlan p;
+    rc = plan_frame(ctx, f, p);
+    if (rc != RT_OK) return rc;
+    const size_t cap = std::max<size_t>(f.pool_cap, std::max<size_t>((size_t)p.n_slots * 2, 1u << 16));
+    // shadow queues hold the whole frame: room for the primary hits and about as many again,
+    // times the number of lights
+    const size_t scap = std::max<size_t>(f.shadow_cap / p.lights1, std::max<size_t>((size_t)p.n_slots * 2, 1u << 16));
+    rc = enqueue_frame(ctx, f, p, cap, scap, true);
+    if (rc != RT_OK) return rc;
+    f.busy = true;
+    ctx->next_slot = id ^ 1u;
+    *ticket_out = id;
+    return RT_OK;
+}
+
+extern "C" int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out) {
+    if (!ctx || ticket > 1) return fail(ctx, RT_ERR_INVALID, "bad ticket");
+    FrameSlot& f = ctx->slot[ticket];
+    if (!f.busy) return fail(ctx, RT_ERR_INVALID, "no frame in flight under this ticket");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int rc = finish_frame(ctx, f, stats_out);
+    f.busy = false;
+    return rc;
+}
+
+extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                                void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {
+    uint32_t ticket = 0;
+    int rc = rt_render_device_begin(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, &ticket);
+    if (rc != RT_OK) return rc;
+    return rt_render_device_end(ctx, ticket, stats_out);
 }
 
 extern "C" int rt_render(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,

@@ -202,3 +202,44 @@ def test_errors_through_the_abi(rtamd, gpu_ctx):
     with pytest.raises(rtamd.RtError) as e:
         rtamd.Scene.from_nff(gpu_ctx, read_nff("extra-nonterminating"))
     assert e.value.code == rtamd.RT_ERR_BUILD
+
+
+def test_two_frames_in_flight(rtamd, oracle, gpu_ctx):
+    """rt_render_device_begin / _end: frames of different views queued back to back (two in flight,
+    on alternating workspaces) give the images of one-at-a-time renders; a third begin without an
+    end is refused; the caller's stream sees each finished image."""
+    import torch
+    text = read_nff("extra-glass")
+    sc = rtamd.Scene.from_nff(gpu_ctx, text)
+    sizes = [(96, 64), (128, 80), (64, 64), (200, 120), (96, 64)]
+    want = [sc.render(rtamd.RenderOptions(max_depth=6), w, h, want_f32=False)[1] for (w, h) in sizes]
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for (w, h) in sizes]
+    copies, tickets = [], []
+    for k, (w, h) in enumerate(sizes):
+        if len(tickets) == 2:
+            st = sc.render_device_end(tickets.pop(0))
+            assert st.rays_primary == sizes[k - 2][0] * sizes[k - 2][1]
+        tickets.append(sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, outs[k].data_ptr(), stream, w, h))
+        copies.append(outs[k].clone())  # queued on the caller's stream right behind the frame
+    with pytest.raises(rtamd.RtError):
+        sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, outs[0].data_ptr(), stream, 96, 64)
+    for t in tickets:
+        sc.render_device_end(t)
+    torch.cuda.synchronize()
+    for k in range(len(sizes)):
+        assert np.array_equal(outs[k].cpu().numpy(), want[k]), k
+        assert np.array_equal(copies[k].cpu().numpy(), want[k]), k
+    # the same output buffer for consecutive frames: each frame's last kernel waits for the copy
+    # the caller queued after the previous frame
+    buf = torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda")
+    snaps = []
+    t0 = sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, buf.data_ptr(), stream, 96, 64)
+    snaps.append(buf.clone())
+    t1 = sc.render_device_begin(rtamd.RenderOptions(max_depth=0), None, buf.data_ptr(), stream, 96, 64)
+    snaps.append(buf.clone())
+    sc.render_device_end(t0)
+    sc.render_device_end(t1)
+    torch.cuda.synchronize()
+    assert np.array_equal(snaps[0].cpu().numpy(), want[0])
+    assert np.array_equal(snaps[1].cpu().numpy(), sc.render(rtamd.RenderOptions(max_depth=0), 96, 64, want_f32=False)[1])
