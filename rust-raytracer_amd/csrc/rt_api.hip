@@ -66,6 +66,9 @@ struct FrameSlot {
     hipEvent_t ev_level[RT_MAX_LEVELS] = {};         // level l intersected and spawned
     hipEvent_t ev_shadow = nullptr;                  // all shadow launches done
     hipEvent_t ev_caller = nullptr;                  // what the caller's stream held when the frame began
+    hipEvent_t ev_done = nullptr;                    // frame finished and its counters copied to the host
+    uint32_t* h_levels = nullptr;                    // pinned copies of `levels` and `counters`, filled by the frame
+    unsigned long long* h_counters = nullptr;        // itself (a blocking copy would wait for the other frame too)
     // the frame in flight
     bool busy = false;
     const rt_scene* scene = nullptr;
@@ -172,6 +175,9 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         for (auto& e : f.ev_level) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_shadow, hipEventDisableTiming));
         RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_caller, hipEventDisableTiming));
+        RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
+        RT_HIP(ctx, hipHostMalloc((void**)&f.h_levels, LV_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        RT_HIP(ctx, hipHostMalloc((void**)&f.h_counters, 20 * sizeof(unsigned long long), hipHostMallocDefault));
         RT_HIP(ctx, f.levels.alloc(LV_WORDS));
         RT_HIP(ctx, f.counters.alloc(20));
     }
@@ -188,6 +194,9 @@ extern "C" void rt_context_destroy(rt_context* ctx) {
             if (e) (void)hipEventDestroy(e);
         if (f.ev_shadow) (void)hipEventDestroy(f.ev_shadow);
         if (f.ev_caller) (void)hipEventDestroy(f.ev_caller);
+        if (f.ev_done) (void)hipEventDestroy(f.ev_done);
+        if (f.h_levels) (void)hipHostFree(f.h_levels);
+        if (f.h_counters) (void)hipHostFree(f.h_counters);
         if (f.shadow_stream) (void)hipStreamDestroy(f.shadow_stream);
         if (f.main_stream) (void)hipStreamDestroy(f.main_stream);
     }
@@ -534,6 +543,9 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     }
     RT_HIP(ctx, hipEventRecord(f.ev[2], st));
     RT_HIP(ctx, hipStreamWaitEvent(f.caller, f.ev[2], 0));
+    RT_HIP(ctx, hipMemcpyAsync(f.h_levels, f.levels.p, LV_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(f.h_counters, f.counters.p, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipEventRecord(f.ev_done, st));
     return RT_OK;
 }
 
@@ -548,8 +560,8 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
     memset(&stats, 0, sizeof(stats));
     uint32_t lv[LV_WORDS];
     for (uint32_t attempt = 0;; ++attempt) {
-        RT_HIP(ctx, hipEventSynchronize(f.ev[2]));
-        RT_HIP(ctx, hipMemcpy(lv, f.levels.p, sizeof(lv), hipMemcpyDeviceToHost));
+        RT_HIP(ctx, hipEventSynchronize(f.ev_done));
+        memcpy(lv, f.h_levels, sizeof(lv));
         if (lv[LV_OVERFLOW] != 0) {  // a pool overflowed: grow and run the frame again
             const size_t shadow_cap1 = f.shadow_cap / p.lights1;
             uint64_t need = p.n_slots, sneed = 0;
@@ -566,7 +578,7 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
             continue;
         }
         unsigned long long c[20];
-        RT_HIP(ctx, hipMemcpy(c, f.counters.p, sizeof(c), hipMemcpyDeviceToHost));
+        memcpy(c, f.h_counters, sizeof(c));
         stats.rays_primary = p.n_primary;
         stats.rays_shadow = 0;
         for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += (uint64_t)lv[LV_SHADOW_COUNT + l] * p.n_lights;

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Runs on the GPU box: frame time of ONE rank's share of the headline frame for N = 1, 2, 4, 8
-(interleaved 8x8 tiles), on a single GPU.  No gather; shows how the per-rank frame shrinks."""
+"""Runs on the GPU box: time per frame of ONE rank's share of the headline frame for N = 1, 2,
+4, 8 (interleaved 8x8 tiles) on a single GPU, one frame at a time and with two frames in
+flight.  No gather; shows how the per-rank frame shrinks."""
 import importlib
 import sys
+import time
 
 import torch
 
@@ -12,12 +14,28 @@ spd = importlib.import_module("rust-raytracer_amd.spd")
 W, H = 3840, 2160
 ctx = rt.Context(0)
 sc = rt.Scene.from_nff(ctx, spd.balls(4, W, H), build_threads=8)
+stream = torch.cuda.current_stream().cuda_stream
 for n in (1, 2, 4, 8):
     px = rt.tile_pixels_max(W, H, n)
     out = torch.zeros((px, 3), dtype=torch.uint8, device="cuda")
     opt = rt.RenderOptions(max_depth=8, tile_rank=0, tile_count=n)
-    ms = []
-    for it in range(4):
-        st = sc.render_device(opt, None, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        ms.append(st.ms_frame)
-    print("N=%d rank 0: %.3f ms/frame, %d rays, ideal %.3f" % (n, min(ms[1:]), st.rays_total, 0.0))
+    for it in range(3):
+        st = sc.render_device(opt, None, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    K = 20
+    t0 = time.perf_counter()
+    for it in range(K):
+        sc.render_device(opt, None, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    one = (time.perf_counter() - t0) / K * 1e3
+    pending = []
+    t0 = time.perf_counter()
+    for it in range(K):
+        if len(pending) == 2:
+            sc.render_device_end(pending.pop(0))
+        pending.append(sc.render_device_begin(opt, None, out.data_ptr(), stream))
+    while pending:
+        sc.render_device_end(pending.pop(0))
+    torch.cuda.synchronize()
+    two = (time.perf_counter() - t0) / K * 1e3
+    print("N=%d rank 0: device frame %.3f ms; wall per frame %.3f ms one at a time, %.3f ms two in flight; %d rays" % (n, st.ms_frame, one, two, st.rays_total))
