@@ -69,8 +69,8 @@ PEAK_PLAIN_TOPS = 39.3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="balls")
     ap.add_argument("--size", type=int, default=4)
     ap.add_argument("--width", type=int, default=3840)
