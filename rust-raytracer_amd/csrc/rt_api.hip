@@ -97,7 +97,7 @@ struct rt_scene {
     DevBuf<float4> sph;
     DevBuf<uint2> sph_id;
     DevBuf<float> bnd;
-    DevBuf<float4> cones, vpos, vnrm, surfaces, lights;
+    DevBuf<float4> cones, poly_plane, vpos, vnrm, surfaces, lights;
     DevBuf<uint32_t> prim_surface;
     DevScene dev{};
 };
@@ -350,8 +350,18 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     RT_HIP(ctx, sc->bnd.upload(bnd));
     RT_HIP(ctx, sc->cone_items.upload(cone_items));
     RT_HIP(ctx, sc->poly_items.upload(poly_items));
-    RT_HIP(ctx, sc->cones.upload(cones));
     RT_HIP(ctx, sc->vpos.upload(vpos));
+    {
+        // The ray-independent part of the cone and polygon tests, by the device's own arithmetic
+        // (the exact build's: no contraction, correctly rounded divide and square root).
+        DevBuf<float4> cones_in;
+        RT_HIP(ctx, cones_in.upload(cones));
+        RT_HIP(ctx, sc->cones.alloc(sd.cones.size() * 4));
+        RT_HIP(ctx, sc->poly_plane.alloc(poly_items.size()));
+        RT_HIP(ctx, rt_exact::launch_prepare_shapes(cones_in.p, (uint32_t)sd.cones.size(), sc->cones.p, sc->poly_items.p,
+                                                    (uint32_t)poly_items.size(), sc->vpos.p, sc->poly_plane.p, nullptr));
+        RT_HIP(ctx, hipStreamSynchronize(nullptr));
+    }
     RT_HIP(ctx, sc->vnrm.upload(vnrm));
     RT_HIP(ctx, sc->surfaces.upload(surfaces));
     RT_HIP(ctx, sc->lights.upload(lights));
@@ -364,6 +374,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.bnd = (const float4*)sc->bnd.p;
     d.cone_items = sc->cone_items.p;
     d.poly_items = sc->poly_items.p;
+    d.poly_plane = sc->poly_plane.p;
     d.cones = sc->cones.p;
     d.vpos = sc->vpos.p;
     d.vnrm = sc->vnrm.p;

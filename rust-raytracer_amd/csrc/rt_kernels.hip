@@ -436,6 +436,27 @@ __global__ void __launch_bounds__(RT_BLOCK) k_appraise(const float* __restrict__
     if (c < 2u * n) cost[c] = r;
 }
 
+// What a shape's test needs of the shape alone, formed once when a scene is uploaded: one
+// thread per cone ({base, radius} {apex, radius} -> {base, radius} {w, axis length} {u, radius
+// difference} {v, -}), then one per polygon entry of the leaf runs (-> polygon_plane).
+__global__ void __launch_bounds__(RT_BLOCK) k_prepare_shapes(const float4* cones_in, uint32_t n_cones, float4* cones,
+                                                             const uint4* poly_items, uint32_t n_items, const float4* vpos,
+                                                             float4* poly_plane) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < n_cones) {
+        const float4 b = cones_in[i * 2], a = cones_in[i * 2 + 1];
+        const ConeFrame f = cone_frame(f3(b.x, b.y, b.z), b.w, f3(a.x, a.y, a.z), a.w);
+        cones[i * 4 + 0] = b;
+        cones[i * 4 + 1] = make_float4(f.w.x, f.w.y, f.w.z, f.mag);
+        cones[i * 4 + 2] = make_float4(f.u.x, f.u.y, f.u.z, f.dr);
+        cones[i * 4 + 3] = make_float4(f.v.x, f.v.y, f.v.z, 0.0f);
+    } else if (i - n_cones < n_items) {
+        const uint32_t k = i - n_cones;
+        const uint32_t first = poly_items[k].z;
+        poly_plane[k] = polygon_plane(from4(vpos[first]), from4(vpos[first + 1]), from4(vpos[first + 2]));
+    }
+}
+
 // Gathered compact tile buffers -> row-major image.  One thread per pixel.
 __global__ void __launch_bounds__(RT_BLOCK) k_deinterleave(DeinterleaveArgs D) {
     const uint64_t p = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -507,12 +528,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
             if (ok) nn = sphere_normal(c, src, ray, t);
             break;
         }
-        case 2:  // RT_OP_CONE
-            ok = isect_cone(f3(a[0], a[1], a[2]), a[3], f3(a[4], a[5], a[6]), a[7], f3(a[8], a[9], a[10]),
-                            f3(a[11], a[12], a[13]), a[14], t, nn);
+        case 2: {  // RT_OP_CONE
+            const F3 base = f3(a[0], a[1], a[2]);
+            const ConeFrame fr = cone_frame(base, a[3], f3(a[4], a[5], a[6]), a[7]);
+            ok = isect_cone(base, a[3], fr, f3(a[8], a[9], a[10]), f3(a[11], a[12], a[13]), a[14], t, nn);
             break;
+        }
         case 3:  // RT_OP_POLYGON
-            ok = isect_polygon(vpos, vnrm, 0u, n_verts, f3(a[0], a[1], a[2]), f3(a[3], a[4], a[5]), a[6], t, nn, ctr);
+            ok = isect_polygon(vpos, vnrm, 0u, n_verts, polygon_plane(from4(vpos[0]), from4(vpos[1]), from4(vpos[2])),
+                               f3(a[0], a[1], a[2]), f3(a[3], a[4], a[5]), a[6], t, nn, ctr);
             break;
         case 4:
         case 5: {  // RT_OP_PHONG / RT_OP_BLINN: surface9, n, v, l, lc
@@ -636,6 +660,15 @@ hipError_t launch_resolve(const FrameArgs& A, uint32_t level, uint32_t grid, hip
 
 hipError_t launch_appraise(const float* boxes6, const uint32_t* list, uint32_t n, uint32_t axis, float* cost, hipStream_t st) {
     hipLaunchKernelGGL(k_appraise, dim3((2u * n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, boxes6, list, n, axis, cost);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_shapes(const float4* cones_in, uint32_t n_cones, float4* cones, const uint4* poly_items,
+                                 uint32_t n_items, const float4* vpos, float4* poly_plane, hipStream_t st) {
+    const uint64_t n = (uint64_t)n_cones + n_items;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prepare_shapes, dim3((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, st, cones_in,
+                       n_cones, cones, poly_items, n_items, vpos, poly_plane);
     return hipGetLastError();
 }
 

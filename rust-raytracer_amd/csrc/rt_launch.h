@@ -21,7 +21,8 @@ struct DevScene {
     const float4* bnd;         // per sphere run: header + bounding records {centre, q}, 8-ary, up to 4 levels
     const uint4* cone_items;   // {primitive, position in the leaf's list, cone index, -}
     const uint4* poly_items;   // {primitive, position in the leaf's list, first vertex, vertex count}
-    const float4* cones;       // 2 per cone: {base, base radius} {apex, apex radius}
+    const float4* poly_plane;  // beside poly_items: {plane normal, edge-loop coordinates} (polygon_plane)
+    const float4* cones;       // 4 per cone: {base, base radius} {w, axis length} {u, radius difference} {v, -} (cone_frame)
     const float4* vpos;        // per vertex {point, 0}
     const float4* vnrm;        // per vertex {normal, 0}
     const float4* surfaces;    // 3 per surface: {color, kd} {ks, shine, reflectance, transmittance} {ior, model bits, -, -}
@@ -90,6 +91,8 @@ struct DeinterleaveArgs {
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \
     hipError_t launch_appraise(const float* boxes6, const uint32_t* list, uint32_t n, uint32_t axis, float* cost,    \
                                hipStream_t st);                                                                      \
+    hipError_t launch_prepare_shapes(const float4* cones_in, uint32_t n_cones, float4* cones, const uint4* poly_items, \
+                                     uint32_t n_items, const float4* vpos, float4* poly_plane, hipStream_t st);      \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
     hipError_t launch_debug_intersect(const rtamd::DevScene& S, bool cull, uint64_t n, const float* src, const float* ray, \
                                       const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist, \

@@ -267,22 +267,56 @@ RT_DEV F3 sphere_normal(F3 c, F3 src, F3 ray, float t) { return normalized(sub(a
 // ---------------------------------------------------------------------------------------
 // Cone / cylinder / frustum without caps, src/cone.rs:97-221
 // ---------------------------------------------------------------------------------------
-RT_DEV_CALL bool isect_cone(F3 base, float br, F3 apex, float ar, F3 src, F3 ray, float near, float& t_out, F3& n_out) {
+// The part of Cone::intersect that does not depend on the ray (src/cone.rs:114-134, and the axis
+// length and radius difference of :155-156): the cone's frame.  It is formed once per cone
+// when a scene is uploaded, by the same operations in the same order, so that a traced ray meets
+// the same bits as if it had recomputed them.
+struct ConeFrame {
+    F3 u, v, w;
+    float mag, dr;
+};
+RT_DEV ConeFrame cone_frame(F3 base, float br, F3 apex, float ar) {
+    ConeFrame f;
     F3 base_to_apex = sub(apex, base);
-    F3 w = normalized(base_to_apex);
+    f.w = normalized(base_to_apex);
     F3 e;
-    if (fabsf(w.x) < fabsf(w.y) && fabsf(w.x) < fabsf(w.z)) e = f3(1.0f, 0.0f, 0.0f);
-    else if (fabsf(w.y) < fabsf(w.z)) e = f3(0.0f, 1.0f, 0.0f);
+    if (fabsf(f.w.x) < fabsf(f.w.y) && fabsf(f.w.x) < fabsf(f.w.z)) e = f3(1.0f, 0.0f, 0.0f);
+    else if (fabsf(f.w.y) < fabsf(f.w.z)) e = f3(0.0f, 1.0f, 0.0f);
     else e = f3(0.0f, 0.0f, 1.0f);
-    F3 u = cross(w, e);
-    F3 v = cross(w, u);
+    f.u = cross(f.w, e);
+    f.v = cross(f.w, f.u);
+    f.mag = magnitude(base_to_apex);
+    f.dr = br - ar;
+    return f;
+}
 
+// (The tests of the big shapes are real calls, to keep the kernels' code small; what they
+// find comes back by value, in registers, not through the stack.)
+struct ShapeHit {
+    float t;
+    F3 n;
+    bool ok;
+};
+RT_DEV bool cone_test(F3 base, float br, const ConeFrame& fr, F3 src, F3 ray, float near, float& t_out, F3& n_out);
+RT_DEV_CALL ShapeHit cone_call(F3 base, float br, ConeFrame fr, F3 src, F3 ray, float near) {
+    ShapeHit h;
+    h.t = 0.0f; h.n = f3(0.0f, 0.0f, 0.0f);
+    h.ok = cone_test(base, br, fr, src, ray, near, h.t, h.n);
+    return h;
+}
+RT_DEV bool isect_cone(F3 base, float br, const ConeFrame& fr, F3 src, F3 ray, float near, float& t_out, F3& n_out) {
+    const ShapeHit h = cone_call(base, br, fr, src, ray, near);
+    t_out = h.t; n_out = h.n;
+    return h.ok;
+}
+RT_DEV bool cone_test(F3 base, float br, const ConeFrame& fr, F3 src, F3 ray, float near, float& t_out, F3& n_out) {
+    const F3 u = fr.u, v = fr.v, w = fr.w;
     F3 base_to_src = sub(src, base);
     F3 S{dot(base_to_src, u), dot(base_to_src, v), dot(base_to_src, w)};
     F3 R{dot(ray, u), dot(ray, v), dot(ray, w)};
 
-    float mag = magnitude(base_to_apex);
-    float dr = br - ar;
+    const float mag = fr.mag;
+    const float dr = fr.dr;
 
     float a = R.x * R.x + R.y * R.y - dr * dr * R.z * R.z / (mag * mag);
     float b = 2.0f * S.x * R.x + 2.0f * S.y * R.y - 2.0f * dr * dr * S.z * R.z / (mag * mag) +
@@ -318,13 +352,43 @@ RT_DEV_CALL bool isect_cone(F3 base, float br, F3 apex, float ar, F3 src, F3 ray
 // an edge (`minor`) and which one the crossing ray runs along (`major`).
 // vpos / vnrm hold one float4 per vertex.
 // ---------------------------------------------------------------------------------------
+//
+// The part that does not depend on the ray, the plane's normal (:61-63) and the pair of
+// coordinates the edge loop works in (:109-110, :165, :211), is formed once per polygon when a
+// scene is uploaded: polygon_plane, by the same operations, so with the same bits.
+// ---------------------------------------------------------------------------------------
+RT_DEV float4 polygon_plane(F3 v0, F3 v1, F3 v2) {  // {normal, minor | major << 2}
+    const F3 gn = cross(sub(v1, v0), sub(v2, v0));
+    uint32_t minor, major;
+    if (fabsf(gn.z) > fabsf(gn.x) && fabsf(gn.z) > fabsf(gn.y)) { minor = 1; major = 0; }
+    else if (fabsf(gn.y) > fabsf(gn.x)) { minor = 2; major = 0; }
+    else { minor = 2; major = 1; }
+    return make_float4(gn.x, gn.y, gn.z, __uint_as_float(minor | (major << 2)));
+}
+
 template <class Ctr>
-RT_DEV_CALL bool isect_polygon(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                          F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
+RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
+                         float4 plane, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr);
+template <class Ctr>
+RT_DEV_CALL ShapeHit polygon_call(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
+                                  float4 plane, F3 src, F3 ray, float near, Ctr& ctr) {
+    ShapeHit h;
+    h.t = 0.0f; h.n = f3(0.0f, 0.0f, 0.0f);
+    h.ok = polygon_test(vpos, vnrm, first, n, plane, src, ray, near, h.t, h.n, ctr);
+    return h;
+}
+template <class Ctr>
+RT_DEV bool isect_polygon(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
+                          float4 plane, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
+    const ShapeHit h = polygon_call(vpos, vnrm, first, n, plane, src, ray, near, ctr);
+    t_out = h.t; n_out = h.n;
+    return h.ok;
+}
+template <class Ctr>
+RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
+                         float4 plane, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
     const F3 v0 = from4(vpos[first]);
-    const F3 v1 = from4(vpos[first + 1]);
-    const F3 v2 = from4(vpos[first + 2]);
-    F3 gn = cross(sub(v1, v0), sub(v2, v0));
+    const F3 gn = f3(plane.x, plane.y, plane.z);
     float den = dot(ray, gn);
     if (fabsf(den) < 0.000001f) return false;
     float num = dot(sub(v0, src), gn);
@@ -332,10 +396,7 @@ RT_DEV_CALL bool isect_polygon(const float4* __restrict__ vpos, const float4* __
     if (plane_dist < near) return false;
 
     F3 in_plane = add(src, mul(ray, plane_dist));
-    uint32_t minor, major;
-    if (fabsf(gn.z) > fabsf(gn.x) && fabsf(gn.z) > fabsf(gn.y)) { minor = 1; major = 0; }
-    else if (fabsf(gn.y) > fabsf(gn.x)) { minor = 2; major = 0; }
-    else { minor = 2; major = 1; }
+    const uint32_t minor = __float_as_uint(plane.w) & 3u, major = __float_as_uint(plane.w) >> 2;
     const float ip_minor = comp(in_plane, minor), ip_major = comp(in_plane, major);
 
     uint32_t count = 0;
@@ -346,7 +407,7 @@ RT_DEV_CALL bool isect_polygon(const float4* __restrict__ vpos, const float4* __
     F3 point = v0;
     for (uint32_t i = 0; i < n; ++i) {
         ctr.poly_edges(1);
-        F3 next_point = (i + 1 < n) ? (i == 0 ? v1 : (i == 1 ? v2 : from4(vpos[first + i + 1]))) : v0;
+        F3 next_point = (i + 1 < n) ? from4(vpos[first + i + 1]) : v0;
         F3 edge = sub(point, next_point);
         float e_minor = comp(edge, minor);
         float np_minor = comp(next_point, minor);

@@ -177,10 +177,16 @@ RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src
         const uint4 it = ld_u4<U>(S.cone_items, first + k);  // {prim, list position, cone index, -}
         if (it.x == ignore) continue;
         ctr.cone_tests(1);
-        const float4 c0 = ld_f4<U>(S.cones, it.z * 2), c1 = ld_f4<U>(S.cones, it.z * 2 + 1);
+        // {base, base radius} {w, axis length} {u, radius difference} {v, -}
+        const float4 c0 = ld_f4<U>(S.cones, it.z * 4), c1 = ld_f4<U>(S.cones, it.z * 4 + 1),
+                     c2 = ld_f4<U>(S.cones, it.z * 4 + 2), c3 = ld_f4<U>(S.cones, it.z * 4 + 3);
+        ConeFrame fr;
+        fr.w = f3(c1.x, c1.y, c1.z); fr.mag = c1.w;
+        fr.u = f3(c2.x, c2.y, c2.z); fr.dr = c2.w;
+        fr.v = f3(c3.x, c3.y, c3.z);
         float t;
         F3 n;
-        if (isect_cone(f3(c0.x, c0.y, c0.z), c0.w, f3(c1.x, c1.y, c1.z), c1.w, src, ray, near, t, n)) {
+        if (isect_cone(f3(c0.x, c0.y, c0.z), c0.w, fr, src, ray, near, t, n)) {
             ctr.cone_hits(1);
             if (lb.better(t, it.y)) {
                 lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
@@ -198,7 +204,7 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
         ctr.poly_tests(1);
         float t;
         F3 n;
-        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, src, ray, near, t, n, ctr)) {
+        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, ld_f4<U>(S.poly_plane, first + k), src, ray, near, t, n, ctr)) {
             ctr.poly_hits(1);
             if (lb.better(t, it.y)) {
                 lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
@@ -311,7 +317,7 @@ RT_DEV void polygons8(const DevScene& S, uint32_t i0, F3 src, F3 ray, float near
         ctr.poly_tests(1);
         float t;
         F3 n;
-        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, src, ray, near, t, n, ctr)) {
+        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, S.poly_plane[i0 + k], src, ray, near, t, n, ctr)) {
             ctr.poly_hits(1);
             if (lb.better(t, it.y)) {
                 lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
