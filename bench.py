@@ -26,6 +26,7 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
                 of rows of the same frame.
 """
 import argparse
+import glob
 import importlib
 import json
 import os
@@ -69,6 +70,19 @@ PEAK_HBM_GBS = 8000.0
 # 4 cycles: 256 CUs x 64 lanes x 2.4 GHz lane-operations per second.  The parity mode may neither
 # fuse nor pack the reference's arithmetic, so this is the ceiling its counted operations can reach.
 PEAK_PLAIN_TOPS = 39.3
+
+
+def measured_traffic(args):
+    """HBM-side bytes of one frame from the committed PMC profile of this exact workload
+    (tools/profile.sh + tools/pmc_sum.py; counters need rocprofv3, so they are not collected
+    inside this run), or None for any other workload."""
+    if (args.scene, args.size, args.width, args.height, args.depth, args.fp) != ("balls", 4, 3840, 2160, 8, "exact"):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_balls4k_depth8_exact_final.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("hbm_bytes_per_frame")
 
 
 def parse_args():
@@ -235,7 +249,7 @@ def main():
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(flops / trace_s / 1e12 / PEAK_F32_TFLOPS, 5),
-            "traffic": None,
+            "traffic": measured_traffic(args),
             "executed_flops_per_frame": flops,
             "executed_bytes_per_frame": abytes,
             "hbm_achieved_GBs": round(abytes / trace_s / 1e9, 3),

@@ -252,8 +252,73 @@ bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, fl
     return Rp == Rp && *r_out < 1e30f;
 }
 
+// ---------------------------------------------------------------------------------------
+// Cylinders: cones whose two radii are equal (as f32 numbers).  What the reference can accept
+// (src/cone.rs:97-221, restated in rt_shapes.h cone_frame + isect_cone), with u = 2^-24:
+//
+// The frame.  w = fl(normalized(apex - base)); U = cross(w, e) for the axis e of w's smallest
+// component is exact in f32 (products with 0 and 1), so U is orthogonal to w and |U|^2 =
+// |w|^2 - w_e^2 >= 2/3; V = fl(cross(w, U)) is within 3.5u |U| of w x U.  The test works in
+// the coordinates S = ((src - base).U, .V, .w), R = (ray.U, .V, .w), each computed within
+// 4u |src - base| |U| resp. 3u |ray| |U| of its exact value.
+//
+// The quadratic.  With equal radii dr = 0 exactly, every term that carries dr is an exact zero,
+// and with Sr = (S.x, S.y), Rr = (R.x, R.y) the computed coefficients are
+//     a = |Rr|^2 (1 + 2u')            -- a sum of squares: no cancellation,
+//     b = 2 Sr.Rr + eb,   |eb| <= 4u |Sr| |Rr|,
+//     c = |Sr|^2 - br^2 + ec,   |ec| <= 3u |Sr|^2 + 2u br^2,
+//     D = fl(b b - 4 a c) = b^2 - 4 a c + eD,   |eD| <= 2u b^2 + 2u |4 a c|.
+// Let t be the exact root (-b -+ sqrt D) / (2a) of these computed numbers; it solves
+// a t^2 + b t + (c - eD/(4a)) = 0, so the point of the computed line at t has
+//     |Sr + t Rr|^2 = br^2 - ec - (a - |Rr|^2) t^2 - eb t + eD/(4a)
+//                  <= br^2 (1 + 4u) + u (13 |Sr|^2 + 8 |Sr| rho + 2 rho^2),   rho = |Sr + t Rr|,
+// which gives rho^2 <= br^2 (1 + 11u) + 17.1u |Sr|^2.  The root the reference really uses is
+// fl((-b -+ fl(sqrt D)) / (2a)) = t + er with |er| |Rr| <= 3.1u (br + |Sr|), so the accepted
+// point X = src + ray r lies, in these coordinates, within
+//     br (1 + 10u) + (sqrt(17.1u) + 3.1u) |Sr|  =  br (1 + 10u) + 1.0098e-3 |Sr|
+// of the axis, and its third coordinate passes the reference's 0 <= w <= |axis| test up to
+// 2u (|axis| + |S.z|).  (near >= 0 is required: for a ray along the axis the reference falls
+// through to a result of -1, which a negative near would accept.)
+//
+// Back to space.  (U, w x U, w) is an orthogonal triple with lengths |U|, |w||U|, |w|, so a
+// coordinate distance d from the axis is a distance of at most d (1 + 6u) / |U| in space, and
+// |Sr| <= |U| |src - base| (1 + 10u).  With C the axis's midpoint, Rc^2 = (|axis|/2)^2 +
+// (br/|U|)^2 and E = src - C this puts X -- a point of the ray's line -- within
+//     Rc (1 + 1.014e-3) + 1.011e-3 |E|
+// of C: the form the sphere hierarchy is built for (r (1 + 3u) + 1.07e-3 |e|) with r = Rc
+// (1 + 1.03e-3).  The same bounds hold for the build that contracts multiply-adds (fewer
+// roundings).  They assume that no product underflows, which would take a ray parallel to a
+// cylinder's axis to within 1e-15 of its length.
+// ---------------------------------------------------------------------------------------
+bool cylinder_bound(const rt_cone& cone, float c_out[3], float* r_out) {
+    if (!(cone.base_radius == cone.apex_radius)) return false;
+    double axis[3], len2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        if (!(std::fabs((double)cone.base[a]) < 1e15) || !(std::fabs((double)cone.apex[a]) < 1e15)) return false;
+        axis[a] = (double)cone.apex[a] - (double)cone.base[a];
+        len2 += axis[a] * axis[a];
+    }
+    const double len = std::sqrt(len2), br = std::fabs((double)cone.base_radius);
+    if (!(len > 1e-15) || !(br < 1e15)) return false;
+    double w_min = 1.0;
+    for (int a = 0; a < 3; ++a) w_min = std::min(w_min, std::fabs(axis[a]) / len);
+    const double u_len = std::sqrt(1.0 - w_min * w_min) * (1.0 - 1e-6);  // |U|, from below (>= 0.81)
+    double cc[3], off2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        const double mid = (double)cone.base[a] + 0.5 * axis[a];
+        c_out[a] = (float)mid;
+        cc[a] = c_out[a];
+        off2 += (cc[a] - mid) * (cc[a] - mid);
+    }
+    const double Rc = std::sqrt(0.25 * len2 + (br / u_len) * (br / u_len));
+    const double Rp = Rc * (1.0 + 1.03e-3) + std::sqrt(off2);
+    *r_out = round_up(Rp);
+    return Rp == Rp && *r_out < 1e30f;
+}
+
 // Block layout in `bnd` (4 floats per record, indices in records):
-//   [h]            header, as integers: {first level-2 record, first level-3, first level-4, top level}
+//   [h]            header, as integers: {first level-2 record, first level-3, first level-4,
+//                  top level | padded entry count << 3}
 //   [h+1]          one record bounding the whole run
 //   [h+2 ...]      level-1 records (one per 8 entries), then levels 2, 3, 4.
 // Record i of level L bounds records 8i .. 8i+7 of level L-1 (entries 8i .. 8i+7 for L = 1).
@@ -285,7 +350,7 @@ uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd) {
     uint32_t top = 4;
     for (int L = 4; L >= 1; --L)
         if (count[L] <= 16) top = (uint32_t)L;
-    const uint32_t hdr[4] = {first[2], first[3], first[4], top};
+    const uint32_t hdr[4] = {first[2], first[3], first[4], top | ((uint32_t)n << 3)};
     memcpy(&bnd[(size_t)h * 4], hdr, sizeof(hdr));
     return h;
 }

@@ -287,8 +287,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             nodes[ni * 4 + 3] = make_uint4(0, 0, 0, 0);
             continue;
         }
-        const uint32_t s0 = (uint32_t)sph.size(), c0 = (uint32_t)cone_items.size(), p0 = (uint32_t)poly_items.size();
-        std::vector<LeafSphere> ls, lp;
+        const uint32_t s0 = (uint32_t)sph.size(), p0 = (uint32_t)poly_items.size();
+        std::vector<LeafSphere> ls, lp, lc;
+        std::vector<uint4> true_cones;
         bool poly_bounds = true;
         for (uint32_t k = 0; k < n.over; ++k) {
             const uint32_t prim = sc->tree.refs[n.under + k];
@@ -297,7 +298,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
                 const rt_sphere& s = sd.spheres[p.index];
                 ls.push_back(LeafSphere{{s.center[0], s.center[1], s.center[2]}, s.radius, prim, k, 0, 0});
             } else if (p.kind == RT_KIND_CONE) {
-                cone_items.push_back(make_uint4(prim, k, p.index, 0));
+                LeafSphere e{{0.0f, 0.0f, 0.0f}, 0.0f, prim, k, p.index, 0};
+                if (cylinder_bound(sd.cones[p.index], e.c, &e.r)) lc.push_back(e);
+                else true_cones.push_back(make_uint4(prim, k, p.index, 0));
             } else {
                 const rt_polygon& pg = sd.polygons[p.index];
                 LeafSphere e{{0.0f, 0.0f, 0.0f}, 0.0f, prim, k, pg.first_vertex, pg.vertex_count};
@@ -312,6 +315,15 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             any_poly_walk = true;
         }
         for (const LeafSphere& e : lp) poly_items.push_back(make_uint4(e.prim, e.pos, e.a0, e.a1));
+        // Cone items: the cylinders first (under a hierarchy of their own when there are enough of
+        // them), then the cones proper, which no sphere can stand in for.
+        uint32_t cu0 = 0xffffffffu;
+        if (lc.size() >= 12) {
+            cu0 = cluster_spheres(lc, bnd);
+        }
+        const uint32_t c0 = (uint32_t)cone_items.size() + (cu0 != 0xffffffffu ? (uint32_t)lc.size() : 0u);
+        for (const LeafSphere& e : lc) cone_items.push_back(make_uint4(e.prim, e.pos, e.a0, 0));
+        cone_items.insert(cone_items.end(), true_cones.begin(), true_cones.end());
         const uint32_t u0 = cluster_spheres(ls, bnd);  // re-ordered, padded to 8, bounding records appended
         const uint32_t ns = (uint32_t)ls.size();
         for (const LeafSphere& e : ls) {
@@ -320,6 +332,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         }
         nodes[ni * 4 + 2] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
         nodes[ni * 4 + 3] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, pu0);
+        nodes[ni * 4 + 0].w = cu0;  // (a leaf has no plane)
     }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;

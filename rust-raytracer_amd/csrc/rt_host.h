@@ -25,11 +25,11 @@ int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err, const Sp
                uint32_t wide_min = 0);
 
 // leaf_cluster.cpp: bounding-sphere groups over one kind of primitive of one leaf
-struct LeafSphere {      // a sphere, or the sphere that stands in for a polygon (polygon_bound)
+struct LeafSphere {      // a sphere, or the sphere that stands in for a polygon or a cylinder (*_bound)
     float c[3];
     float r;
     uint32_t prim, pos;  // primitive id, position in the leaf's list
-    uint32_t a0, a1;     // polygons: first vertex, vertex count
+    uint32_t a0, a1;     // polygons: first vertex, vertex count; cylinders: cone index, -
 };
 // Re-orders `v` spatially, pads it to a multiple of 8 entries (padding = copies of entries with
 // bit 31 of `pos` set), and appends the run's block of bounding records to `bnd` (4 floats each);
@@ -39,6 +39,10 @@ uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd);
 // a ray, the ray's line passes within r + 1.1e-5 |src - c| of c.  False if no such bound exists
 // (coordinates that are not finite).
 bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, float c[3], float* r);
+// The same for a cone with equal radii and a query with near >= 0 (Cone::intersect, reference
+// src/cone.rs:97-221): the line passes within r + 1.011e-3 |src - c| of c.  False for any other
+// cone (its quadratic's leading coefficient can cancel, and then no such bound holds).
+bool cylinder_bound(const rt_cone& cone, float c[3], float* r);
 
 // Validates counts, pointers and every index in a scene description.
 int validate_desc(const rt_scene_desc& d, std::string& err);

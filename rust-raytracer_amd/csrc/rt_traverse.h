@@ -175,7 +175,7 @@ RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src
                        LeafBest& lb, Ctr& ctr) {
     for (uint32_t k = 0; k < count; ++k) {
         const uint4 it = ld_u4<U>(S.cone_items, first + k);  // {prim, list position, cone index, -}
-        if (it.x == ignore) continue;
+        if (it.x == ignore || (it.y >> 31) != 0u) continue;  // (bit 31: a padding copy of another entry)
         ctr.cone_tests(1);
         // {base, base radius} {w, axis length} {u, radius difference} {v, -}
         const float4 c0 = ld_f4<U>(S.cones, it.z * 4), c1 = ld_f4<U>(S.cones, it.z * 4 + 1),
@@ -326,9 +326,16 @@ RT_DEV void polygons8(const DevScene& S, uint32_t i0, F3 src, F3 ray, float near
     }
 }
 
-// POLY: the run holds polygons, each bounded by the sphere polygon_bound (leaf_cluster.cpp)
-// derives for it; the records and their test are the same.
-template <bool POLY, bool BEHIND, class Ctr>
+// The 8 cylinders of items i0 .. i0+7 (padding copies skipped).
+template <class Ctr>
+RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    leaf_cones<false>(S, i0, 8u, src, ray, near, ignore, lb, ctr);
+}
+
+// KIND 1: the run holds polygons, KIND 2: cones with equal radii; each is bounded by the sphere
+// polygon_bound / cylinder_bound (leaf_cluster.cpp) derives for it, and the records and their
+// test are the same as for spheres (KIND 0).
+template <int KIND, bool BEHIND, class Ctr>
 RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, float a,
                           float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
     const float4 hf = S.bnd[header];
@@ -336,7 +343,7 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
     const bool fwd = near >= 0.0f;
     if (!bound_may_hit<BEHIND>(S.bnd[header + 1u], src, ray, a, fwd)) return;  // misses the whole run
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
-                   off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w);
+                   off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w) & 7u;
     const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
     auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : off4)); };
     auto level_n = [&](uint32_t L) { return L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : n4)); };
@@ -353,7 +360,8 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             }
             const uint32_t k = (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
-            if constexpr (POLY) polygons8(S, first + (g * 8u + k) * 8u, src, ray, near, ignore, lb, ctr);
+            if constexpr (KIND == 1) polygons8(S, first + (g * 8u + k) * 8u, src, ray, near, ignore, lb, ctr);
+            else if constexpr (KIND == 2) cylinders8(S, first + (g * 8u + k) * 8u, src, ray, near, ignore, lb, ctr);
             else cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
         }
     };
@@ -459,6 +467,7 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     while (!done) {
         // ---- walk until this lane stands on a leaf whose box it hits, or is finished
         bool at_leaf = false;
+        uint32_t leaf_w = 0xffffffffu;  // a leaf's fourth word: header of its cylinder run's records, or none
         uint4 q2 = make_uint4(0, 0, 0, 0), q3 = make_uint4(0, 0, 0, 0);
         while (!done && !at_leaf) {
             const uint4 q0 = S.nodes[cur * 4 + 0];
@@ -471,6 +480,7 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                 const uint32_t axis = q1.w;
                 if (axis == AXIS_LEAF) {
                     q3 = S.nodes[cur * 4 + 3];
+                    leaf_w = q0.w;
                     at_leaf = true;
                 } else {
                     ctr.interior_steps(1);
@@ -489,17 +499,30 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
         if (at_leaf) {
             LeafBest lb;
             lb.init();
+            uint32_t cyl_n = 0u;  // cylinders of the leaf that have bounding records (the cone items before q2.z)
+            if constexpr (!LEAN) {
+                if (leaf_w != 0xffffffffu) cyl_n = __float_as_uint(S.bnd[leaf_w].w) >> 3;
+            }
             if constexpr (MODE != 0) {
                 if (q2.y >= CULL_MIN_SPHERES) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_run_lane<false, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                    leaf_run_lane<0, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
                     q2.y = 0u;
                 }
                 if constexpr (!LEAN) {
                     if (q3.w != 0xffffffffu && tame) {  // polygon run with bounding records
-                        leaf_run_lane<true, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                        leaf_run_lane<1, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
                         q3.y = 0u;
                     }
+                    if (cyl_n != 0u && tame && near >= 0.0f) {  // cylinder run with bounding records
+                        leaf_run_lane<2, MODE == 2>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, a, near, ignore, lb, ctr, lane_words,
+                                                    stride);
+                        cyl_n = 0u;
+                    }
                 }
+            }
+            if constexpr (!LEAN) {  // cylinders not walked above go with the cones, which they precede
+                q2.z -= cyl_n;
+                q2.w += cyl_n;
             }
             // What is left (short runs, cones, rays the bounding test cannot take): entry by entry.
             // Long lists are walked by all lanes standing on the same leaf together, index

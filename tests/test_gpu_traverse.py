@@ -207,3 +207,98 @@ def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offs
     fp, fd, fn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST | rtamd.DEBUG_EXHAUSTIVE)
     cp, cd, cn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST)
     assert np.array_equal(cp, fp) and np.array_equal(bits(cd), bits(fd)) and np.array_equal(bits(cn), bits(fn))
+
+
+def cylinder_cloud(rng, n, scale, offset):
+    """A floor over a cloud of cylinders (``c`` with equal radii): oblique, axis-aligned, needles,
+    discs, plus a few cones proper, which stay outside the bounding records."""
+    lines = ["v", "from %g %g %g" % tuple(offset + scale * np.array([3.0, 3.0, 2.0])), "at %g %g %g" % tuple(offset),
+             "up 0 0 1", "angle 40", "hither %g" % (scale * 1e-3), "resolution 32 32", "l %g %g %g" % tuple(offset + 5 * scale),
+             "f 1 0.5 0.5 0.5 0.5 3 0 0", "p 4"]
+    for sx, sy in ((-30, -30), (30, -30), (30, 30), (-30, 30)):
+        lines.append("%.9g %.9g %.9g" % (offset[0] + sx * scale, offset[1] + sy * scale, offset[2] - 1.5 * scale))
+    cyl = []
+    for k in range(n):
+        c = offset + rng.uniform(-1, 1, 3) * scale
+        length = scale * 10.0 ** rng.uniform(-2.5, -0.5)
+        radius = scale * 10.0 ** rng.uniform(-3.0, -1.0)
+        axis = rng.normal(size=3)
+        kind = k % 6
+        if kind == 1:    # along a coordinate axis
+            axis = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])
+        elif kind == 2:  # two equal components (the frame's choice of axis is a tie)
+            axis = np.array([1.0, 1.0, rng.uniform(1.0, 3.0)])[rng.permutation(3)]
+        elif kind == 3:  # needle
+            radius = length * 1e-3
+        elif kind == 4:  # disc
+            radius = length * 30.0
+        axis = axis / np.linalg.norm(axis)
+        base = (c - axis * length / 2).astype(np.float32)
+        apex = (c + axis * length / 2).astype(np.float32)
+        r = np.float32(radius)
+        ra = r if k % 97 else np.float32(radius * 0.5)  # (a cone proper now and then)
+        cyl.append((base, apex, r, ra))
+        lines.append("c")
+        lines.append("%.9g %.9g %.9g %.9g" % (base[0], base[1], base[2], r))
+        lines.append("%.9g %.9g %.9g %.9g" % (apex[0], apex[1], apex[2], ra))
+    return "\n".join(lines) + "\n", cyl
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, (0.0, 0.0, 0.0)), (1.0, (1000.0, 1000.0, 500.0)), (1e-3, (0.5, 0.25, -0.125))])
+def test_cylinder_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset):
+    """Big leaves skip groups of cylinders through the spheres that stand in for them.  Same bar
+    as for spheres and polygons: primitive, distance bits and normal bits of the culled walk equal
+    the exhaustive walk and the oracle, for rays grazing a cylinder's surface, rays (almost)
+    along its axis or along its surface, origins on the axis, on cylinders and far away,
+    unnormalised rays, and near values below zero (which the culled walk must not take)."""
+    rng = np.random.default_rng(29)
+    offset = np.array(offset, np.float64)
+    text, cyl = cylinder_cloud(rng, 2001, scale, offset)
+    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    o = oracle.OracleScene(text, build_threads=4)
+    assert o.info.max_leaf > 1000
+    n = 40000
+    pick = rng.integers(0, len(cyl), n)
+    tgt = np.zeros((n, 3))
+    along = np.zeros((n, 3))
+    tangent = np.zeros((n, 3))
+    for i, k in enumerate(pick):
+        base, apex, r, _ = cyl[k]
+        base, apex = base.astype(np.float64), apex.astype(np.float64)
+        w = (apex - base) / np.linalg.norm(apex - base)
+        p = np.cross(w, rng.normal(size=3)); p /= np.linalg.norm(p)
+        h = rng.uniform(-0.1, 1.1)
+        rad = float(r) * rng.choice([1.0, 1.0, 1.0 + 1e-6, 1.0 - 1e-6, 0.3, 0.0])
+        tgt[i] = base + (apex - base) * h + p * rad
+        along[i] = w
+        tangent[i] = np.cross(w, p)
+    far = rng.choice([0.3, 1.5, 4.0, 60.0, 3000.0], n)[:, None]
+    src = offset + rng.normal(size=(n, 3)) * scale * far
+    mode = rng.integers(0, 8, n)
+    # 1: along the axis direction towards the target (parallel to the axis, on or off it)
+    back = rng.uniform(0.5, 40.0, (n, 1)) * scale
+    src = np.where((mode == 1)[:, None], tgt - along * back, src)
+    # 2: almost along it
+    src = np.where((mode == 2)[:, None], tgt - along * back + rng.normal(size=(n, 3)) * back * 10.0 ** rng.uniform(-8, -3, (n, 1)), src)
+    # 3: grazing: along the tangent through a surface point
+    src = np.where((mode == 3)[:, None], tgt - tangent * back, src)
+    start = rng.integers(0, len(cyl), n)
+    on = mode == 4                # origins on another cylinder's axis (inside it)
+    src = np.where(on[:, None], np.stack([(cyl[k][0].astype(np.float64) + cyl[k][1]) / 2 for k in start]), src)
+    d = tgt - src
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-300)
+    d *= rng.choice([1.0, 1.0, 0.01, 250.0], n)[:, None]
+    src, d = src.astype(np.float32), d.astype(np.float32)
+    near = rng.choice(np.array([0.0, 0.0, 1e-4, -0.25, -2.0], np.float32) * np.float32(scale), n).astype(np.float32)
+    near = np.where(rng.random(n) < 0.05, np.float32(-2.0), near).astype(np.float32)  # (below the -1 the reference falls back to)
+    ignore = np.where(rng.random(n) < 0.3, np.where(on, start, pick) + 1, 0xFFFFFFFF).astype(np.uint32)
+    wp, wd, wn = o.intersect_rays(src, d, near, ignore)
+    ep, ed, en = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_EXHAUSTIVE)
+    gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
+    assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
+    assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    hit = wp != 0xFFFFFFFF
+    assert 0.05 < (hit & (wp != 0)).mean() < 0.98
+    fp, fd, fn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST | rtamd.DEBUG_EXHAUSTIVE)
+    cp, cd, cn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST)
+    assert np.array_equal(cp, fp) and np.array_equal(bits(cd), bits(fd)) and np.array_equal(bits(cn), bits(fn))

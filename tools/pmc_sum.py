@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc output (counter_collection.csv files under a directory) per kernel and
-counter.  usage: tools/pmc_sum.py <dir> > summary.csv"""
+counter.  usage: tools/pmc_sum.py <dir> [traffic.json] > summary.csv
+
+With a second argument it also writes the memory-side bytes of one timed frame: FETCH_SIZE and
+WRITE_SIZE (KiB) of the kernels a timed frame launches, FETCH_SIZE doubled (on gfx950 it tallies
+128-byte requests at 64 bytes), divided by the number of frames in the run."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -24,6 +29,27 @@ def main():
     w.writerow(["kernel", "counter", "sum_over_dispatches", "dispatches"])
     for key in sorted(sums):
         w.writerow([key[0], key[1], sums[key], len(disp[key])])
+    if len(sys.argv) > 2:
+        # timed frames launch the NoCounters kernels; k_resolve runs in every frame, instrumented or not
+        frames_timed = max((len(d) for k, d in disp.items() if "k_intersect<true" in k[0] and "NoCounters" in k[0]
+                            and k[1] == "FETCH_SIZE"), default=0)
+        frames_all = max((len(d) for k, d in disp.items() if "k_resolve<true>" in k[0] and k[1] == "FETCH_SIZE"), default=0)
+        per = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+        for (kernel, counter), v in sums.items():
+            if counter not in per:
+                continue
+            if "NoCounters" in kernel and frames_timed:
+                per[counter] += v * 1024.0 / frames_timed
+            elif "k_resolve" in kernel and frames_all:
+                per[counter] += v * 1024.0 / frames_all
+        out = {"frames": frames_timed, "fetch_bytes_per_frame": int(2 * per["FETCH_SIZE"]),
+               "write_bytes_per_frame": int(per["WRITE_SIZE"]),
+               "hbm_bytes_per_frame": int(2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]),
+               "method": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, per-kernel sums of the timed "
+                         "frames' kernels, FETCH_SIZE x 2 (gfx950), / frames"}
+        with open(sys.argv[2], "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
 
 
 if __name__ == "__main__":
