@@ -591,11 +591,10 @@ hipError_t init_kernels() {
                          (const void*)k_intersect<true, 0, NoCounters>, (const void*)k_intersect<true, 1, NoCounters>,
                          (const void*)k_intersect<false, 0, WorkCounters>, (const void*)k_intersect<false, 2, WorkCounters>,
                          (const void*)k_intersect<false, 0, NoCounters>, (const void*)k_intersect<false, 2, NoCounters>,
-                         (const void*)k_shadow<0, WorkCounters>, (const void*)k_shadow<1, WorkCounters>,
-                         (const void*)k_shadow<2, WorkCounters>, (const void*)k_shadow<0, NoCounters>,
-                         (const void*)k_shadow<1, NoCounters>, (const void*)k_shadow<2, NoCounters>,
+                         (const void*)k_shadow<0, WorkCounters>, (const void*)k_shadow<2, WorkCounters>,
+                         (const void*)k_shadow<0, NoCounters>, (const void*)k_shadow<2, NoCounters>,
                          (const void*)k_intersect<true, 5, NoCounters>, (const void*)k_intersect<false, 6, NoCounters>,
-                         (const void*)k_shadow<5, NoCounters>, (const void*)k_shadow<6, NoCounters>,
+                         (const void*)k_shadow<6, NoCounters>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -629,17 +628,15 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
                          hipStream_t st) {
     const size_t lds = stack_bytes(A.scene);
     const dim3 g(grid, A.scene.n_lights), b(RT_BLOCK);
-    const int mode = !cull ? 0 : (first_level == 0 ? 1 : 2);  // deeper levels' hits lie among the spheres
+    // shadow rays start on a surface, among the primitives, at every level: the behind-origin test pays
+    const int mode = cull ? 2 : 0;
     const bool lean = A.scene.lean != 0;
     if (work) {
         if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level);
-        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, WorkCounters>), g, b, lds, st, A, first_level, last_level);
         else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, first_level, last_level);
     } else {
         if (mode == 2 && lean) hipLaunchKernelGGL((k_shadow<6, NoCounters>), g, b, lds, st, A, first_level, last_level);
-        else if (mode == 1 && lean) hipLaunchKernelGGL((k_shadow<5, NoCounters>), g, b, lds, st, A, first_level, last_level);
         else if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, first_level, last_level);
-        else if (mode == 1) hipLaunchKernelGGL((k_shadow<1, NoCounters>), g, b, lds, st, A, first_level, last_level);
         else hipLaunchKernelGGL((k_shadow<0, NoCounters>), g, b, lds, st, A, first_level, last_level);
     }
     return hipGetLastError();
