@@ -207,6 +207,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    traffic = measured_traffic(args)
     flops = sum(work[k] * (c - FLOP_SAVED.get(k, 0)) for k, c in FLOP.items())
     nodes_frame = work["rays_primary"] + work["rays_reflect"] + work["rays_refract"]
     abytes = sum(work[k] * c for k, c in BYTES.items()) + nodes_frame * RAY_STATE_BYTES + W * H * FRAMEBUFFER_BYTES
@@ -249,12 +250,13 @@ def main():
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(flops / trace_s / 1e12 / PEAK_F32_TFLOPS, 5),
-            "traffic": measured_traffic(args),
+            "traffic": traffic,
             "executed_flops_per_frame": flops,
-            "executed_bytes_per_frame": abytes,
-            "hbm_achieved_GBs": round(abytes / trace_s / 1e9, 3),
+            # bytes the counted tests request; the scene is cache resident, so most never reach HBM
+            "requested_bytes_per_frame": abytes,
+            "hbm_achieved_GBs": round(traffic / trace_s / 1e9, 3) if traffic else None,
             "hbm_peak_GBs": PEAK_HBM_GBS,
-            "hbm_frac": round(abytes / trace_s / 1e9 / PEAK_HBM_GBS, 6),
+            "hbm_frac": round(traffic / trace_s / 1e9 / PEAK_HBM_GBS, 6) if traffic else None,
             "plain_op_ceiling": {"achieved": round(flops / trace_s / 1e12, 4), "peak": PEAK_PLAIN_TOPS, "unit": "Tops/s",
                                  "frac": round(flops / trace_s / 1e12 / PEAK_PLAIN_TOPS, 5)},
             "walk_lane_use": round((work["bound_tests"] + work["sphere_tests"]) / work["lane_slots"], 4)
