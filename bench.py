@@ -53,7 +53,8 @@ FLOP = {"node_visits": 27, "interior_steps": 4, "sphere_tests": 26, "sphere_hits
         "light_evals": 16, "shade_evals": 37, "surface_hits": 15, "rays_reflect": 20, "rays_refract": 31,
         "rays_primary": 25,
         # bounding-sphere test of the culled leaf walk (rt_traverse.h bound_may_hit): 3 sub,
-        # 2 mul + 5 fma, 2 mul, 1 compare
+        # 2 mul + 5 fma, 1 mul, 1 compare = 17 for the line test; + 1 fma, 1 compare = 20 with the
+        # behind-origin test (every kernel but the camera rays'); 18 is charged
         "bound_tests": 18}
 BYTES = {"node_visits": 64, "sphere_tests": 16, "cone_tests": 32, "poly_edges": 24, "light_evals": 24,
          "shade_evals": 36, "bound_tests": 16}

@@ -18,11 +18,11 @@
 //     dist(line, C) <= R' + k0 |E|,   R' = R (1 + 1.07e-3).
 // Since 2 k0 R' |E| <= alpha R'^2 + (k0^2 / alpha) |E|^2 for any alpha > 0,
 //     (R' + k0 |E|)^2 <= R'^2 (1 + alpha) + k0^2 (1 + 1/alpha) |E|^2.
-// The device rejects the group iff  a * (|E|^2 (1 - beta) - q) > (ray.E)^2,  which in exact
-// arithmetic means dist(line, C)^2 > q + beta |E|^2.  With alpha = 1/16, q = R'^2 (1 + alpha)
-// rounded up, and beta = 2.2e-5 >= k0^2 * 17 (1.95e-5) + 16u (the f32 error of evaluating the
-// test itself, relative to a |E|^2: 9u in (ray.E)^2, 7u in the left side), a rejected group
-// holds no sphere the reference could accept.
+// The device rejects the group iff  |E|^2 (1 - beta) - q > (n.E)^2  with n = ray / |ray|, which
+// in exact arithmetic means dist(line, C)^2 > q + beta |E|^2.  With alpha = 1/16, q = R'^2
+// (1 + alpha) rounded up, and beta = 2.2e-5 >= k0^2 * 17 (1.95e-5) + 22.1u (the f32 error of
+// evaluating the test itself, relative to |E|^2: 9u in (n.E)^2, 6.1u from n's own rounding,
+// 7u in the left side), a rejected group holds no sphere the reference could accept.
 #include <algorithm>
 #include <cmath>
 #include <cstring>

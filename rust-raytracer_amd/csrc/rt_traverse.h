@@ -219,11 +219,13 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
 // level 4; each record is a bounding sphere {C, q} built on the host (leaf_cluster.cpp, which
 // also derives the bound and the layout).  A group is skipped only when the reference's test
 // cannot accept ANY sphere inside it:
-//     a * (|E|^2 * (1 - beta) - q) > (ray . E)^2,   E = src - C,  beta = 2.2e-5,
+//     |E|^2 * (1 - beta) - q > (n . E)^2,   E = src - C,  n = ray / |ray|,  beta = 2.2e-5,
 // which implies dist(line, C)^2 > q + beta' |E|^2 >= the widest the reference's f32 evaluation
 // of b*b - 4ac can stretch any enclosed sphere (q carries the bounding radius with its margin).
 // Skipping changes no result: every skipped sphere would have been rejected.  This test is not
-// part of the reference's arithmetic, so it may use FMA.
+// part of the reference's arithmetic, so it may use FMA, and it works with the ray's direction
+// normalised once per ray (unit_ray): each component of n is within 3u of exact, which moves
+// (n . E)^2 by at most 6.1u |E|^2 -- part of what beta allows for (leaf_cluster.cpp).
 //
 // The walk is split in two loops so that the lanes of a wave run the same code on different
 // data: first a depth-first descent whose only step is "test the 8 records of one group"
@@ -239,34 +241,37 @@ constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - LANE_STACK;
 
 // BEHIND adds the second way out, for rays that start among the spheres: the whole bounding
 // sphere lies behind the ray's origin,
-//     ray . E > 0  and  (ray . E)^2 > a * (q + beta |E|^2),
-// so every enclosed sphere could only be hit at t < 0 <= near.  `fwd` is false for a query
-// with near < 0, which must not use it.
+//     n . E > 0  and  (n . E)^2 > q + beta |E|^2,
+// so every enclosed sphere could only be hit at t < 0 <= near: a query with near < 0 must not
+// be walked with it.  Both conditions read s = d |d|, the signed square of d = n . E.
 template <bool BEHIND>
-RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 ray, float a, bool fwd) {
+RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 n) {
     const float ex = src.x - rec.x, ey = src.y - rec.y, ez = src.z - rec.z;
-    const float d = __builtin_fmaf(ray.z, ez, __builtin_fmaf(ray.y, ey, ray.x * ex));
+    const float d = __builtin_fmaf(n.z, ez, __builtin_fmaf(n.y, ey, n.x * ex));
     const float ee = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
     const float t = __builtin_fmaf(ee, CULL_ONE_MINUS_BETA, -rec.w);
-    const float dd = d * d;
-    bool keep = !(a * t > dd);  // NaN anywhere keeps the group
+    const float s = d * fabsf(d);
+    bool keep = !(t > fabsf(s));  // NaN anywhere keeps the group
     if constexpr (BEHIND) {
         const float u = __builtin_fmaf(ee, CULL_BETA, rec.w);
-        keep = keep && !(fwd && d > 0.0f && dd > a * u);
+        keep = keep && !(s > u);
     }
     return keep;
 }
 
+// The ray's direction at unit length for the bounding tests (a = |ray|^2, finite and normal).
+RT_DEV F3 unit_ray(F3 ray, float a) { return mul(ray, 1.0f / sqrtf(a)); }
+
 // Live mask of the records base[0..8), of which the first `valid` exist (the array is padded
 // so that all 8 loads are in bounds).
 template <bool BEHIND, class Ctr>
-RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 ray, float a, bool fwd, Ctr& ctr) {
+RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 n, Ctr& ctr) {
     float4 r[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) r[k] = base[k];
     uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) m |= bound_may_hit<BEHIND>(r[k], src, ray, a, fwd) ? (1u << k) : 0u;
+    for (int k = 0; k < 8; ++k) m |= bound_may_hit<BEHIND>(r[k], src, n) ? (1u << k) : 0u;
     ctr.bound_tests(8);
     if constexpr (Ctr::kEnabled) {
         if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true)))
@@ -336,12 +341,11 @@ RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, float nea
 // polygon_bound / cylinder_bound (leaf_cluster.cpp) derives for it, and the records and their
 // test are the same as for spheres (KIND 0).
 template <int KIND, bool BEHIND, class Ctr>
-RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, float a,
+RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, F3 un, float a,
                           float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
     const float4 hf = S.bnd[header];
     ctr.bound_tests(1);
-    const bool fwd = near >= 0.0f;
-    if (!bound_may_hit<BEHIND>(S.bnd[header + 1u], src, ray, a, fwd)) return;  // misses the whole run
+    if (!bound_may_hit<BEHIND>(S.bnd[header + 1u], src, un)) return;  // misses the whole run
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
                    off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w) & 7u;
     const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
@@ -399,7 +403,7 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             }
             g = g * 8u + k;  // record g*8+k of level L = group of that index one level down
             L -= 1u;
-            m = expand8<BEHIND>(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, ray, a, fwd, ctr);
+            m = expand8<BEHIND>(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, un, ctr);
         }
     }
     drain();
@@ -453,9 +457,12 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     const uint32_t stride = blockDim.x;
     uint2* my_stack = stack + threadIdx.x;
     uint32_t* lane_words = (uint32_t*)(stack + S.stack_depth * stride) + threadIdx.x;  // RT_LANE_WORDS per lane, same stride
-    // the bounding-record test assumes that its intermediate values stay finite
-    const bool tame = a > 0.0f && a < 1e16f && dot(src, src) < 1e16f;
+    // The bounding-record tests assume that their intermediate values stay finite and normal,
+    // and the one that looks behind the origin that hits before the origin do not count.
     constexpr int MODE = CULL & 3;
+    const bool tame = a >= 1e-30f && a < 1e16f && dot(src, src) < 1e16f && (MODE != 2 || near >= 0.0f);
+    F3 un = ray;
+    if constexpr (MODE != 0) un = unit_ray(ray, a);
     constexpr bool LEAN = (CULL & 4) != 0;
     uint32_t sp = 0;
     uint32_t cur = 0;
@@ -504,18 +511,18 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                 if (leaf_w != 0xffffffffu) cyl_n = __float_as_uint(S.bnd[leaf_w].w) >> 3;
             }
             if constexpr (MODE != 0) {
-                if (q2.y >= CULL_MIN_SPHERES) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_run_lane<0, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                if (q2.y >= CULL_MIN_SPHERES && tame) {  // big sphere run: this lane's own walk of its bounding records
+                    leaf_run_lane<0, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride);
                     q2.y = 0u;
                 }
                 if constexpr (!LEAN) {
                     if (q3.w != 0xffffffffu && tame) {  // polygon run with bounding records
-                        leaf_run_lane<1, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, a, near, ignore, lb, ctr, lane_words, stride);
+                        leaf_run_lane<1, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride);
                         q3.y = 0u;
                     }
                     if (cyl_n != 0u && tame && near >= 0.0f) {  // cylinder run with bounding records
-                        leaf_run_lane<2, MODE == 2>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, a, near, ignore, lb, ctr, lane_words,
-                                                    stride);
+                        leaf_run_lane<2, MODE == 2>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, un, a, near, ignore, lb, ctr,
+                                                    lane_words, stride);
                         cyl_n = 0u;
                     }
                 }
