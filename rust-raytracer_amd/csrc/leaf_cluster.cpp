@@ -316,6 +316,11 @@ bool cylinder_bound(const rt_cone& cone, float c_out[3], float* r_out) {
     return Rp == Rp && *r_out < 1e30f;
 }
 
+void sphere_record(const LeafSphere& e, float out[4]) {
+    const std::vector<LeafSphere> one(1, e);
+    bound(one, 0, 1, out);
+}
+
 // Block layout in `bnd` (4 floats per record, indices in records):
 //   [h]            header, as integers: {first level-2 record, first level-3, first level-4,
 //                  top level | padded entry count << 3}

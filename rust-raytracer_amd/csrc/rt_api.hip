@@ -97,7 +97,7 @@ struct rt_scene {
     DevBuf<float4> sph;
     DevBuf<uint2> sph_id;
     DevBuf<float> bnd;
-    DevBuf<float4> cones, poly_plane, vpos, vnrm, surfaces, lights;
+    DevBuf<float4> cones, poly_plane, poly_bound, cone_bound, vpos, vnrm, surfaces, lights;
     DevBuf<uint32_t> prim_surface;
     DevScene dev{};
 };
@@ -279,6 +279,12 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     std::vector<uint2> sph_id;
     std::vector<float> bnd;  // 4 floats per record
     std::vector<uint4> cone_items, poly_items;
+    std::vector<float4> cone_bound, poly_bound;  // one record per item, for the item alone
+    auto push_record = [](std::vector<float4>& to, const LeafSphere& e) {
+        float rec[4];
+        sphere_record(e, rec);
+        to.push_back(make_float4(rec[0], rec[1], rec[2], rec[3]));
+    };
     bool any_poly_walk = false;
     for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
         const rt_kd_node& n = sc->tree.nodes[ni];
@@ -304,7 +310,11 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             } else {
                 const rt_polygon& pg = sd.polygons[p.index];
                 LeafSphere e{{0.0f, 0.0f, 0.0f}, 0.0f, prim, k, pg.first_vertex, pg.vertex_count};
-                poly_bounds = poly_bounds && polygon_bound(sd.vertices.data(), pg.first_vertex, pg.vertex_count, e.c, &e.r);
+                if (!polygon_bound(sd.vertices.data(), pg.first_vertex, pg.vertex_count, e.c, &e.r)) {
+                    poly_bounds = false;
+                    e.c[0] = e.c[1] = e.c[2] = 0.0f;
+                    e.r = INFINITY;
+                }
                 lp.push_back(e);
             }
         }
@@ -314,7 +324,10 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             pu0 = cluster_spheres(lp, bnd);
             any_poly_walk = true;
         }
-        for (const LeafSphere& e : lp) poly_items.push_back(make_uint4(e.prim, e.pos, e.a0, e.a1));
+        for (const LeafSphere& e : lp) {
+            poly_items.push_back(make_uint4(e.prim, e.pos, e.a0, e.a1));
+            push_record(poly_bound, e);
+        }
         // Cone items: the cylinders first (under a hierarchy of their own when there are enough of
         // them), then the cones proper, which no sphere can stand in for.
         uint32_t cu0 = 0xffffffffu;
@@ -322,8 +335,12 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             cu0 = cluster_spheres(lc, bnd);
         }
         const uint32_t c0 = (uint32_t)cone_items.size() + (cu0 != 0xffffffffu ? (uint32_t)lc.size() : 0u);
-        for (const LeafSphere& e : lc) cone_items.push_back(make_uint4(e.prim, e.pos, e.a0, 0));
+        for (const LeafSphere& e : lc) {
+            cone_items.push_back(make_uint4(e.prim, e.pos, e.a0, 0));
+            push_record(cone_bound, e);
+        }
         cone_items.insert(cone_items.end(), true_cones.begin(), true_cones.end());
+        cone_bound.insert(cone_bound.end(), true_cones.size(), make_float4(0.0f, 0.0f, 0.0f, INFINITY));
         const uint32_t u0 = cluster_spheres(ls, bnd);  // re-ordered, padded to 8, bounding records appended
         const uint32_t ns = (uint32_t)ls.size();
         for (const LeafSphere& e : ls) {
@@ -363,6 +380,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     RT_HIP(ctx, sc->bnd.upload(bnd));
     RT_HIP(ctx, sc->cone_items.upload(cone_items));
     RT_HIP(ctx, sc->poly_items.upload(poly_items));
+    RT_HIP(ctx, sc->poly_bound.upload(poly_bound));
+    RT_HIP(ctx, sc->cone_bound.upload(cone_bound));
     RT_HIP(ctx, sc->vpos.upload(vpos));
     {
         // The ray-independent part of the cone and polygon tests, by the device's own arithmetic
@@ -388,6 +407,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.cone_items = sc->cone_items.p;
     d.poly_items = sc->poly_items.p;
     d.poly_plane = sc->poly_plane.p;
+    d.poly_bound = sc->poly_bound.p;
+    d.cone_bound = sc->cone_bound.p;
     d.cones = sc->cones.p;
     d.vpos = sc->vpos.p;
     d.vnrm = sc->vnrm.p;
@@ -396,7 +417,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.lights = sc->lights.p;
     d.n_lights = (uint32_t)sd.lights.size();
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
-    d.lean = (cone_items.empty() && !any_poly_walk) ? 1u : 0u;
+    // lean: no cones and next to no polygons (a floor): kernels without the code for either's records
+    d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8) ? 1u : 0u;
     memcpy(d.bg, sd.background, sizeof(d.bg));
     // the per-lane traversal stack lives in LDS: depth * 8 B * RT_BLOCK lanes per block
     if ((size_t)d.stack_depth * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t) > 160 * 1024)

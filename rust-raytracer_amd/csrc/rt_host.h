@@ -35,6 +35,8 @@ struct LeafSphere {      // a sphere, or the sphere that stands in for a polygon
 // bit 31 of `pos` set), and appends the run's block of bounding records to `bnd` (4 floats each);
 // returns the index of the block's header record.
 uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd);
+// The bounding record {C, q} of one entry alone (q = inf when its radius is not finite: never culled).
+void sphere_record(const LeafSphere& e, float out[4]);
 // Sphere {c, r} such that whenever Polygon::intersect (reference src/polygon.rs:58-293) accepts
 // a ray, the ray's line passes within r + 1.1e-5 |src - c| of c.  False if no such bound exists
 // (coordinates that are not finite).

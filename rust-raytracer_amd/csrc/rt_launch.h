@@ -22,6 +22,8 @@ struct DevScene {
     const uint4* cone_items;   // {primitive, position in the leaf's list, cone index, -}
     const uint4* poly_items;   // {primitive, position in the leaf's list, first vertex, vertex count}
     const float4* poly_plane;  // beside poly_items: {plane normal, edge-loop coordinates} (polygon_plane)
+    const float4* poly_bound;  // beside poly_items: bounding record {C, q} of the polygon alone
+    const float4* cone_bound;  // beside cone_items: the same for a cylinder; q = inf for a cone proper
     const float4* cones;       // 4 per cone: {base, base radius} {w, axis length} {u, radius difference} {v, -} (cone_frame)
     const float4* vpos;        // per vertex {point, 0}
     const float4* vnrm;        // per vertex {normal, 0}

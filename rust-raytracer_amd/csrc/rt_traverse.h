@@ -170,12 +170,25 @@ RT_DEV void leaf_spheres(const DevScene& S, uint32_t first, uint32_t count, F3 s
     }
 }
 
-template <bool U, class Ctr>
-RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, float near, uint32_t ignore,
-                       LeafBest& lb, Ctr& ctr) {
+template <bool BEHIND>
+RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 n);
+
+// BND: 0 = every entry gets the reference's test; 1 / 2 = a cylinder or polygon is first tried
+// through its own bounding record (cone_bound / poly_bound, the sphere its *_bound function in
+// leaf_cluster.cpp derives; 2 = also the behind-origin way out), `ok` saying whether this ray
+// may use the records (un = its unit direction).  The full tests cost 5 to 10 times a record's.
+template <bool U, int BND, class Ctr>
+RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, F3 un, bool ok, float near,
+                       uint32_t ignore, LeafBest& lb, Ctr& ctr) {
     for (uint32_t k = 0; k < count; ++k) {
         const uint4 it = ld_u4<U>(S.cone_items, first + k);  // {prim, list position, cone index, -}
         if (it.x == ignore || (it.y >> 31) != 0u) continue;  // (bit 31: a padding copy of another entry)
+        if constexpr (BND != 0) {
+            if (ok) {
+                ctr.bound_tests(1);
+                if (!bound_may_hit<BND == 2>(ld_f4<U>(S.cone_bound, first + k), src, un)) continue;
+            }
+        }
         ctr.cone_tests(1);
         // {base, base radius} {w, axis length} {u, radius difference} {v, -}
         const float4 c0 = ld_f4<U>(S.cones, it.z * 4), c1 = ld_f4<U>(S.cones, it.z * 4 + 1),
@@ -195,12 +208,18 @@ RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src
     }
 }
 
-template <bool U, class Ctr>
-RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, float near,
+template <bool U, int BND, class Ctr>
+RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, F3 un, bool ok, float near,
                           uint32_t ignore, LeafBest& lb, Ctr& ctr) {
     for (uint32_t k = 0; k < count; ++k) {
         const uint4 it = ld_u4<U>(S.poly_items, first + k);  // {prim, list position, first vertex, n vertices}
         if (it.x == ignore || (it.y >> 31) != 0u) continue;  // (bit 31: a padding copy of another entry)
+        if constexpr (BND != 0) {
+            if (ok) {
+                ctr.bound_tests(1);
+                if (!bound_may_hit<BND == 2>(ld_f4<U>(S.poly_bound, first + k), src, un)) continue;
+            }
+        }
         ctr.poly_tests(1);
         float t;
         F3 n;
@@ -313,28 +332,16 @@ RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, fl
     }
 }
 
-// The 8 polygons of items i0 .. i0+7 (padding copies skipped).
-template <class Ctr>
-RT_DEV void polygons8(const DevScene& S, uint32_t i0, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
-    for (uint32_t k = 0; k < 8u; ++k) {
-        const uint4 it = S.poly_items[i0 + k];
-        if (it.x == ignore || (it.y >> 31) != 0u) continue;
-        ctr.poly_tests(1);
-        float t;
-        F3 n;
-        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, S.poly_plane[i0 + k], src, ray, near, t, n, ctr)) {
-            ctr.poly_hits(1);
-            if (lb.better(t, it.y)) {
-                lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
-            }
-        }
-    }
+// The 8 polygons / cylinders of items i0 .. i0+7 (padding copies skipped), each behind its own record.
+template <bool BEHIND, class Ctr>
+RT_DEV void polygons8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, float near, uint32_t ignore, LeafBest& lb,
+                      Ctr& ctr) {
+    leaf_polygons<false, BEHIND ? 2 : 1>(S, i0, 8u, src, ray, un, true, near, ignore, lb, ctr);
 }
-
-// The 8 cylinders of items i0 .. i0+7 (padding copies skipped).
-template <class Ctr>
-RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
-    leaf_cones<false>(S, i0, 8u, src, ray, near, ignore, lb, ctr);
+template <bool BEHIND, class Ctr>
+RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, float near, uint32_t ignore, LeafBest& lb,
+                       Ctr& ctr) {
+    leaf_cones<false, BEHIND ? 2 : 1>(S, i0, 8u, src, ray, un, true, near, ignore, lb, ctr);
 }
 
 // KIND 1: the run holds polygons, KIND 2: cones with equal radii; each is bounded by the sphere
@@ -364,8 +371,8 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             }
             const uint32_t k = (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
-            if constexpr (KIND == 1) polygons8(S, first + (g * 8u + k) * 8u, src, ray, near, ignore, lb, ctr);
-            else if constexpr (KIND == 2) cylinders8(S, first + (g * 8u + k) * 8u, src, ray, near, ignore, lb, ctr);
+            if constexpr (KIND == 1) polygons8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
+            else if constexpr (KIND == 2) cylinders8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
             else cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
         }
     };
@@ -409,12 +416,12 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
     drain();
 }
 
-template <bool U, class Ctr>
-RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, float a, float near, uint32_t ignore,
-                      LeafBest& lb, Ctr& ctr) {
+template <bool U, int BND, class Ctr>
+RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, F3 un, bool ok_cone, bool ok_poly, float a,
+                      float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
     if (q2.y) leaf_spheres<U>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
-    if (q2.w) leaf_cones<U>(S, q2.z, q2.w, src, ray, near, ignore, lb, ctr);
-    if (q3.y) leaf_polygons<U>(S, q3.x, q3.y, src, ray, near, ignore, lb, ctr);
+    if (q2.w) leaf_cones<U, BND>(S, q2.z, q2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
+    if (q3.y) leaf_polygons<U, BND>(S, q3.x, q3.y, src, ray, un, ok_poly, near, ignore, lb, ctr);
 }
 
 // Result of a finished subtree against the pending stack entries: returns true and sets
@@ -464,6 +471,8 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     F3 un = ray;
     if constexpr (MODE != 0) un = unit_ray(ray, a);
     constexpr bool LEAN = (CULL & 4) != 0;
+    constexpr int BND = LEAN ? 0 : MODE;  // (a lean scene has no cones and next to no polygons)
+    const bool ok_cone = tame && near >= 0.0f;
     uint32_t sp = 0;
     uint32_t cur = 0;
     bool done = false;
@@ -546,17 +555,17 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                                                     __builtin_amdgcn_readfirstlane(q2.z), __builtin_amdgcn_readfirstlane(q2.w));
                         const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y),
                                                     0u, 0u);
-                        if constexpr (MODE != 0) leaf_cones<true>(S, u2.z, u2.w, src, ray, near, ignore, lb, ctr);
-                        else leaf_runs<true>(S, u2, u3, src, ray, a, near, ignore, lb, ctr);
+                        if constexpr (MODE != 0) leaf_cones<true, BND>(S, u2.z, u2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
+                        else leaf_runs<true, 0>(S, u2, u3, src, ray, un, false, false, a, near, ignore, lb, ctr);
                         mine_done = true;
                     }
                 }
                 if constexpr (MODE != 0) {
                     q2.w = 0u;
-                    leaf_runs<false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
+                    leaf_runs<false, BND>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
                 }
             } else {
-                leaf_runs<false>(S, q2, q3, src, ray, a, near, ignore, lb, ctr);
+                leaf_runs<false, BND>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
             }
             r_hit = lb.have;
             if (lb.have) {
