@@ -543,7 +543,7 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
             // What is left (short runs, cones, rays the bounding test cannot take): entry by entry.
             // Long lists are walked by all lanes standing on the same leaf together, index
             // wave-uniform (entries arrive by scalar loads); the culling kernels only keep that
-            // path for cones, the one kind without bounding records.
+            // path for the cone items (cones proper, and cylinders too few for a hierarchy).
             if constexpr (LEAN) q2.w = 0u;  // (there are no cones)
             const uint32_t together = MODE != 0 ? q2.w : q2.y + q2.w + q3.y;
             if (together >= BIG_LEAF) {
