@@ -508,6 +508,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
     float* o = out + i * os;
     NoCounters ctr;
     RayInv ri;
+    ri.inv = f3(0.0f, 0.0f, 0.0f);
+    ri.quick = false;
     float t = 0.0f;
     F3 nn = f3(0, 0, 0);
     bool ok = false;

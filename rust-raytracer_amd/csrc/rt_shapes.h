@@ -193,9 +193,50 @@ RT_DEV F3 shade_blinn_phong(const Surface& s, F3 normal, F3 view, F3 ldir, F3 lc
 // ---------------------------------------------------------------------------------------
 // Axis-aligned box slab test, src/shape.rs:84-172.  bmax is fl(corner + extent).
 // ---------------------------------------------------------------------------------------
-struct RayInv {  // fast build only: per-ray reciprocals of the direction
+struct RayInv {  // per-ray reciprocals of the direction
     F3 inv;
+    bool quick;  // exact build: the ray may use aabb_quick
 };
+
+// The box test decided from quotients formed as (corner - src) * fl(1 / ray), when that is
+// safe.  Each such product is within 3u (u = 2^-24) of the quotient the reference rounds
+// (1/ray: u, the product: u, the reference's own rounding: u), and so are the largest near and
+// the smallest far value taken over the axes, relative to themselves.  The reference's answer
+// (smallest_far >= largest_near && smallest_far >= near_cull) is therefore known whenever the
+// approximate values keep those two comparisons clear by 6.2u resp. 3.1u of their size (plus
+// 1e-37 for products that underflow); then `hit` is the reference's answer and the function
+// returns true.  Otherwise -- a ray that grazes a box edge to the last bits, an infinity, a
+// NaN -- it returns false and the caller runs the reference's divisions.  The ray must have
+// no component other than zero outside 1e-30 .. 1e30 in size (RayInv::quick), so that the
+// reciprocals are finite and normal.
+RT_DEV bool aabb_quick(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, F3 inv, bool& hit) {
+    const F3 to_min = sub(bmin, src);
+    const F3 to_max = sub(bmax, src);
+    float n = -3.402823466e+38f, f = 3.402823466e+38f;
+    bool outside = false;  // a zero component with the origin outside that slab: a miss (src/shape.rs:84-172)
+    if (ray.x != 0.0f) {
+        const float a = to_min.x * inv.x, b = to_max.x * inv.x;
+        n = fminf(a, b); f = fmaxf(a, b);
+    } else {
+        outside = src.x < bmin.x || src.x > bmax.x;
+    }
+    if (ray.y != 0.0f) {
+        const float a = to_min.y * inv.y, b = to_max.y * inv.y;
+        n = fmaxf(n, fminf(a, b)); f = fminf(f, fmaxf(a, b));
+    } else {
+        outside = outside || src.y < bmin.y || src.y > bmax.y;
+    }
+    if (ray.z != 0.0f) {
+        const float a = to_min.z * inv.z, b = to_max.z * inv.z;
+        n = fmaxf(n, fminf(a, b)); f = fminf(f, fmaxf(a, b));
+    } else {
+        outside = outside || src.z < bmin.z || src.z > bmax.z;
+    }
+    const float m1 = __builtin_fmaf(fmaxf(fabsf(f), fabsf(n)), 3.7e-7f, 1e-37f);  // 6.2u
+    const float m2 = __builtin_fmaf(fabsf(f), 1.85e-7f, 1e-37f);                  // 3.1u
+    hit = !outside && f >= n && f >= near_cull;
+    return outside || (fabsf(f - n) > m1 && fabsf(f - near_cull) > m2);
+}
 
 RT_DEV bool aabb_slab_test(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, const RayInv& ri) {
     float largest_near = -3.402823466e+38f;  // std::f32::MIN

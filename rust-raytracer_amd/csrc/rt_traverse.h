@@ -457,9 +457,12 @@ template <int CULL, class Ctr>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr) {
     RayInv ri;
-#if RT_FAST
     ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
-#endif
+    {
+        const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
+        ri.quick = (ax == 0.0f || (ax >= 1e-30f && ax <= 1e30f)) && (ay == 0.0f || (ay >= 1e-30f && ay <= 1e30f)) &&
+                   (az == 0.0f || (az >= 1e-30f && az <= 1e30f));
+    }
     const float a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
     const uint32_t stride = blockDim.x;
     uint2* my_stack = stack + threadIdx.x;
@@ -491,7 +494,15 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
             ctr.node_visits(1);
             const F3 bmin = f3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
             const F3 bmax = f3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
-            if (aabb_slab_test(bmin, bmax, src, ray, near, ri)) {  // :276-279
+#if RT_FAST
+            const bool in_box = aabb_slab_test(bmin, bmax, src, ray, near, ri);
+#else
+            // the reference's six divisions only where the quotients' order is in doubt
+            bool in_box = false;
+            if (!ri.quick || !aabb_quick(bmin, bmax, src, ray, near, ri.inv, in_box))
+                in_box = aabb_slab_test(bmin, bmax, src, ray, near, ri);
+#endif
+            if (in_box) {  // :276-279
                 q2 = S.nodes[cur * 4 + 2];
                 const uint32_t axis = q1.w;
                 if (axis == AXIS_LEAF) {
