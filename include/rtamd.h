@@ -261,6 +261,13 @@ enum {
  * out_stride floats per row.  `verts`/`n_verts`: polygon vertex list for RT_OP_POLYGON. */
 int rt_debug_eval(rt_context* ctx, uint32_t op, uint32_t fp_mode, uint64_t n, const float* in, uint32_t in_stride,
                   float* out, uint32_t out_stride, const rt_vertex* verts, uint32_t n_verts);
+/* Diagnostic, host only (no reference counterpart): the sphere {centre, radius} that stands in
+ * for one primitive in the leaf walk's bounding records -- kind RT_KIND_CONE: `cone` (only
+ * cones with equal radii have one), RT_KIND_POLYGON: `verts[0 .. n_verts)`.  Whenever the
+ * reference's test of that primitive accepts a ray (near >= 0 for a cone), the accepted point
+ * lies within radius + k |src - centre| of the centre, k = 1.011e-3 (cone) or 1.1e-5 (polygon).
+ * Returns 1 and fills out4, or 0 when the primitive has no such sphere. */
+int rt_debug_bound(uint32_t kind, const rt_cone* cone, const rt_vertex* verts, uint32_t n_verts, float* out4);
 
 #ifdef __cplusplus
 }

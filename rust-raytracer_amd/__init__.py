@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
+    "rt_debug_bound",
 )
 
 
@@ -197,6 +198,8 @@ def lib():
     L.rt_tree_free.restype = None
     L.rt_camera_basis.argtypes = [C.POINTER(rt_view), vp]
     L.rt_camera_basis.restype = None
+    L.rt_debug_bound.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp]
+    L.rt_debug_bound.restype = C.c_int
     L.rt_debug_intersect.argtypes = [vp, vp, C.c_uint32, C.c_uint64] + [vp] * 7
     L.rt_debug_eval.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
     _lib = L
@@ -448,6 +451,18 @@ def write_ppm(path: str, rgb_u8: np.ndarray):
     rc = lib().rt_ppm_write(path.encode(), w, h, _ptr(rgb_u8))
     if rc != RT_OK:
         raise RtError(rc, f"cannot write {path}")
+
+
+def debug_bound(kind, cone8=None, verts6=None):
+    """The sphere (centre xyz, radius) standing in for one primitive in the bounding records
+    (rt_debug_bound), or None.  cone8: base xyz, base radius, apex xyz, apex radius;
+    verts6: [n, 6] points and normals."""
+    out = np.zeros(4, dtype=np.float32)
+    cone = np.ascontiguousarray(cone8, dtype=np.float32) if cone8 is not None else None
+    verts = np.ascontiguousarray(verts6, dtype=np.float32) if verts6 is not None else None
+    ok = lib().rt_debug_bound(kind, _ptr(cone) if cone is not None else None, _ptr(verts) if verts is not None else None,
+                              0 if verts is None else verts.shape[0], _ptr(out))
+    return out if ok else None
 
 
 def tile_pixels(width, height, rank, count):

@@ -116,6 +116,13 @@ Camera camera_basis(const rt_view& v) {
 
 using namespace rtamd;
 
+extern "C" int rt_debug_bound(uint32_t kind, const rt_cone* cone, const rt_vertex* verts, uint32_t n_verts, float* out4) {
+    if (!out4) return 0;
+    if (kind == RT_KIND_CONE && cone) return cylinder_bound(*cone, out4, out4 + 3) ? 1 : 0;
+    if (kind == RT_KIND_POLYGON && verts && n_verts >= 3) return polygon_bound(verts, 0, n_verts, out4, out4 + 3) ? 1 : 0;
+    return 0;
+}
+
 extern "C" void rt_camera_basis(const rt_view* view, float* out9) {
     Camera c = camera_basis(*view);
     memcpy(out9, c.forward, 12);
