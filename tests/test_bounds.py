@@ -107,3 +107,39 @@ def test_polygon_stand_in_sphere_holds_every_accepted_point(oracle):
             accepted += int(hit.sum())
     assert accepted > 20000
     assert worst <= 0.0, worst
+
+
+def test_sphere_acceptance_margin_of_the_bounding_records(oracle):
+    """What the sphere records are built on: the reference accepts a sphere only for a line
+    within r (1 + 3u) + sqrt(19u) |src - c| of its centre (leaf_cluster.cpp)."""
+    rng = np.random.default_rng(7)
+    u = 2.0 ** -24
+    worst, accepted = -1.0, 0
+    for k in range(100):
+        r = 10.0 ** rng.uniform(-3, 1)
+        c = (rng.normal(size=3) * 10.0 ** rng.uniform(-1, 2)).astype(np.float32)
+        data8 = np.zeros(8, np.float32)
+        data8[:3] = c
+        data8[3] = r
+        r = float(data8[3])
+        n = 5000
+        far = 10.0 ** rng.uniform(-1, 4.5, (n, 1)) * r
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        p = np.cross(d, rng.normal(size=(n, 3)))
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+        miss = r * rng.uniform(0.99, 1.01, (n, 1)) + far * rng.random((n, 1)) * 1.2e-3
+        src = (c.astype(np.float64) + p * miss - d * far).astype(np.float32)
+        ray = (d * rng.choice([1.0, 0.03, 40.0], (n, 1))).astype(np.float32)
+        hit, _, _ = oracle.shape_batch(0, data8, None, src, ray, np.zeros(n, np.float32))
+        hit = hit.astype(bool)
+        if hit.any():
+            e = src[hit].astype(np.float64) - c.astype(np.float64)
+            dd = ray[hit].astype(np.float64)
+            dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+            line = np.linalg.norm(e - (e * dd).sum(1, keepdims=True) * dd, axis=1)
+            allowed = r * (1 + 3 * u) + np.sqrt(19 * u) * np.linalg.norm(e, axis=1)
+            worst = max(worst, float((line / allowed).max()))
+            accepted += int(hit.sum())
+    assert accepted > 20000
+    assert 0.3 < worst <= 1.0, worst  # (the rays do reach into the margin)
