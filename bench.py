@@ -141,7 +141,7 @@ def main():
     pending, stats = [], []
 
     def step():
-        if len(pending) == 2:
+        if len(pending) == ctx.frames_in_flight:
             stats.append(scene.render_device_end(pending.pop(0)))
         target = image if world == 1 else mine
         pending.append(scene.render_device_begin(opt, None, target.data_ptr(), stream))
@@ -243,7 +243,7 @@ def main():
         },
         "frame_ms": {"trace_kernels": round(float(mx[6]), 4), "resolve_kernels": round(float(mx[7]), 4),
                      "device_frame": round(float(mx[8]), 4), "step_wall": round(ms_per_step, 4),
-                     "frames_in_flight": 2},
+                     "frames_in_flight": ctx.frames_in_flight},
         "roofline": {
             "bound": "valu",
             "kernel": "trace phase of one frame: k_intersect + k_shadow + k_light of every bounce level, two streams",

@@ -192,15 +192,18 @@ int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view
 /* The same frame in two steps, for callers that render frame after frame (no counterpart in the
  * reference, which renders one image and exits).  rt_render_device_begin puts the frame on the
  * GPU and returns at once; rt_render_device_end waits for it, re-runs it with larger ray pools
- * if they overflowed, and fills the statistics.  At most two frames may be in flight: the
- * small launches that end one frame then run beside the big launches that start the next.
+ * if they overflowed, and fills the statistics.  At most rt_frames_in_flight(ctx) frames may
+ * be in flight (2; 1 to 4 with the environment variable RTAMD_FRAMES_IN_FLIGHT read when the
+ * context is created), begun and ended in the same order: the small launches that end one
+ * frame then run beside the big launches that start the next.
  * Only the frame's last kernel touches the output buffers, and it is ordered after everything
  * `stream` held when begin was called; `stream` in turn waits for the frame, so work queued on
- * it afterwards (a copy, a gather) sees the finished image.  Tickets are 0 and 1; a ticket is
- * free again once rt_render_device_end has returned. */
+ * it afterwards (a copy, a gather) sees the finished image.  A ticket is free again once
+ * rt_render_device_end has returned. */
 int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                            void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out);
 int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out);
+uint32_t rt_frames_in_flight(const rt_context* ctx);
 
 /* ---- interleaved 8x8 tiles over ranks (pure index math + one device kernel) ---- */
 

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
-    "rt_debug_bound",
+    "rt_debug_bound", "rt_frames_in_flight",
 )
 
 
@@ -200,6 +200,8 @@ def lib():
     L.rt_camera_basis.restype = None
     L.rt_debug_bound.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp]
     L.rt_debug_bound.restype = C.c_int
+    L.rt_frames_in_flight.argtypes = [vp]
+    L.rt_frames_in_flight.restype = C.c_uint32
     L.rt_debug_intersect.argtypes = [vp, vp, C.c_uint32, C.c_uint64] + [vp] * 7
     L.rt_debug_eval.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
     _lib = L
@@ -307,6 +309,11 @@ class Context:
             self._h = None
             raise RtError(rc, msg)
         self.device = device
+
+    @property
+    def frames_in_flight(self) -> int:
+        """How many frames render_device_begin may have queued at once."""
+        return int(lib().rt_frames_in_flight(self._h))
 
     def check(self, rc):
         if rc != RT_OK:

@@ -79,10 +79,13 @@ struct FrameSlot {
     hipStream_t caller = nullptr;
 };
 
+constexpr uint32_t RT_MAX_FRAME_SLOTS = 4;
+
 struct rt_context {
     int device = 0;
     std::string err;
-    FrameSlot slot[2];
+    FrameSlot slot[RT_MAX_FRAME_SLOTS];  // all set up, the first n_slots in use
+    uint32_t n_slots = 2;
     uint32_t next_slot = 0;
     DevBuf<float> out_f32;
     DevBuf<uint8_t> out_u8;
@@ -168,6 +171,10 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
     RT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, RT_ERR_UNSUPPORTED, std::string("librtamd is built for gfx950 only; device is ") + prop.gcnArchName);
+    // Frames in flight: two keep one GPU busy with whole frames; a rank that renders a small
+    // share of a frame (1/8 of the tiles) is bound by launch latency and gains from more.
+    if (const char* s = getenv("RTAMD_FRAMES_IN_FLIGHT"))
+        ctx->n_slots = std::min<uint32_t>(RT_MAX_FRAME_SLOTS, std::max<uint32_t>(1, (uint32_t)strtoul(s, nullptr, 10)));
     for (FrameSlot& f : ctx->slot) {
         for (auto& e : f.ev) RT_HIP(ctx, hipEventCreate(&e));
         RT_HIP(ctx, hipStreamCreateWithFlags(&f.main_stream, hipStreamNonBlocking));
@@ -668,7 +675,7 @@ extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, co
     if (rc != RT_OK) return rc;
     const uint32_t id = ctx->next_slot;
     FrameSlot& f = ctx->slot[id];
-    if (f.busy) return fail(ctx, RT_ERR_INVALID, "two frames are in flight already: call rt_render_device_end first");
+    if (f.busy) return fail(ctx, RT_ERR_INVALID, "every frame slot is in flight already: call rt_render_device_end first");
     f.scene = scene;
     f.view = *view;
     f.opt = *opt;
@@ -685,13 +692,13 @@ extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, co
     rc = enqueue_frame(ctx, f, p, cap, scap, true);
     if (rc != RT_OK) return rc;
     f.busy = true;
-    ctx->next_slot = id ^ 1u;
+    ctx->next_slot = (id + 1u) % ctx->n_slots;
     *ticket_out = id;
     return RT_OK;
 }
 
 extern "C" int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out) {
-    if (!ctx || ticket > 1) return fail(ctx, RT_ERR_INVALID, "bad ticket");
+    if (!ctx || ticket >= ctx->n_slots) return fail(ctx, RT_ERR_INVALID, "bad ticket");
     FrameSlot& f = ctx->slot[ticket];
     if (!f.busy) return fail(ctx, RT_ERR_INVALID, "no frame in flight under this ticket");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -699,6 +706,8 @@ extern "C" int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* 
     f.busy = false;
     return rc;
 }
+
+extern "C" uint32_t rt_frames_in_flight(const rt_context* ctx) { return ctx ? ctx->n_slots : 0; }
 
 extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                                 void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {

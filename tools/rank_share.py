@@ -31,11 +31,11 @@ for n in (1, 2, 4, 8):
     pending = []
     t0 = time.perf_counter()
     for it in range(K):
-        if len(pending) == 2:
+        if len(pending) == ctx.frames_in_flight:
             sc.render_device_end(pending.pop(0))
         pending.append(sc.render_device_begin(opt, None, out.data_ptr(), stream))
     while pending:
         sc.render_device_end(pending.pop(0))
     torch.cuda.synchronize()
     two = (time.perf_counter() - t0) / K * 1e3
-    print("N=%d rank 0: device frame %.3f ms; wall per frame %.3f ms one at a time, %.3f ms two in flight; %d rays" % (n, st.ms_frame, one, two, st.rays_total))
+    print("N=%d rank 0: device frame %.3f ms; wall per frame %.3f ms one at a time, %.3f ms with %d in flight; %d rays" % (n, st.ms_frame, one, two, ctx.frames_in_flight, st.rays_total))
