@@ -269,7 +269,7 @@ def main():
         },
     }
 
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:  # (the CPU baseline is a single-GPU-run figure: rank 0, N = 1)
         out["cpu_baseline"], out["parity_sample"] = cpu_baseline(args, text, image)
     print(json.dumps(out), flush=True)
     if world > 1:
