@@ -98,6 +98,7 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--fp", choices=["exact", "fast"], default="exact")
     ap.add_argument("--cpu-rows", type=int, default=8, help="rows of the frame the CPU baseline renders per leg")
+    ap.add_argument("--lights", type=int, default=0, help="mount only: number of point lights")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -117,6 +118,10 @@ def main():
     spd = importlib.import_module("rust-raytracer_amd.spd")
     W, H = args.width, args.height
     gen_kw = {"size": args.size} if args.scene in ("balls", "tetra", "rings", "mount") else {}
+    if args.scene == "lathe" and args.size > 4:  # (lathe: --size = patches around; half as many along)
+        gen_kw = {"nu": args.size, "nv": args.size // 2}
+    if args.scene == "mount" and args.lights:
+        gen_kw["lights"] = args.lights
     text = spd.GENERATORS[args.scene](width=W, height=H, **gen_kw)
 
     ctx = rtamd.Context(local_rank)

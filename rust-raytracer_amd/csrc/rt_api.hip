@@ -425,11 +425,10 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.n_lights = (uint32_t)sd.lights.size();
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
     // lean: no cones and next to no polygons (a floor): kernels without the code for either's records
-    d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8) ? 1u : 0u;
+    d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8 && d.stack_depth <= RT_STACK_RING) ? 1u : 0u;
     memcpy(d.bg, sd.background, sizeof(d.bg));
-    // the per-lane traversal stack lives in LDS: depth * 8 B * RT_BLOCK lanes per block
-    if ((size_t)d.stack_depth * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t) > 160 * 1024)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "space partition deeper than the device traversal stack (80 levels)");
+    if (d.stack_depth > RT_STACK_RING + RT_STACK_DEEP)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "space partition deeper than the device traversal stack (64 levels)");
     *out = sc.release();
     return RT_OK;
 }

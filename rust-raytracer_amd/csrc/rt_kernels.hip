@@ -582,8 +582,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
 // host-callable launchers (one set per namespace)
 // ---------------------------------------------------------------------------------------
 // traversal stack + the per-lane words of the culled leaf walk
-static size_t stack_bytes(const DevScene& S) {
-    return (size_t)S.stack_depth * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t);
+// (the lean kernels keep the whole stack in LDS, the others its newest RT_STACK_RING entries)
+static size_t stack_bytes(const DevScene& S, bool lean_kernel) {
+    const size_t entries = lean_kernel ? S.stack_depth : RT_STACK_RING;
+    return entries * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t);
 }
 
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
@@ -607,9 +609,9 @@ hipError_t init_kernels() {
 
 // `work` selects the instrumented kernels, `cull` the culled walk of big leaves.
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
-    const size_t lds = stack_bytes(A.scene);
     const dim3 g(grid), b(RT_BLOCK);
     const bool lean = A.scene.lean != 0;
+    const size_t lds = stack_bytes(A.scene, !work && cull && lean);
     if (level == 0) {  // camera rays start outside the scene: the line test alone
         if (work && cull) hipLaunchKernelGGL((k_intersect<true, 1, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<true, 0, WorkCounters>), g, b, lds, st, A, level);
@@ -628,7 +630,7 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 
 hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, uint32_t grid,
                          hipStream_t st) {
-    const size_t lds = stack_bytes(A.scene);
+    const size_t lds = stack_bytes(A.scene, !work && cull && A.scene.lean != 0);
     const dim3 g(grid, A.scene.n_lights), b(RT_BLOCK);
     // shadow rays start on a surface, among the primitives, at every level: the behind-origin test pays
     const int mode = cull ? 2 : 0;
@@ -681,8 +683,8 @@ hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, cons
                                   const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist,
                                   float* out_normal, hipStream_t st) {
     const dim3 g((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), b(RT_BLOCK);
-    if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
-    else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     return hipGetLastError();
 }
 

@@ -6,7 +6,14 @@
 
 #define RT_BLOCK 256
 #define RT_MAX_LEVELS 64  // max_depth + 2 must fit
-#define RT_LANE_WORDS 16   // per-lane LDS words of the culled leaf walk, after the traversal stack
+#define RT_LANE_WORDS 16
+// Traversal stack of the general kernels: the newest RT_STACK_RING entries of a lane sit in LDS,
+// older ones in the lane's private memory, so that a deep tree does not cost occupancy (every
+// 8 levels of an all-LDS stack take 16 KiB per block of 256 lanes); RT_STACK_DEEP entries there.
+// The "lean" kernels keep the whole stack in LDS and are only used on trees up to
+// RT_STACK_RING levels deep.
+#define RT_STACK_RING 8
+#define RT_STACK_DEEP 56   // per-lane LDS words of the culled leaf walk, after the traversal stack
 
 namespace rtamd {
 
@@ -31,7 +38,7 @@ struct DevScene {
     const uint32_t* prim_surface;
     const float4* lights;      // 2 per light: {position, 0} {color, 0}
     uint32_t n_lights;
-    uint32_t stack_depth;      // entries per lane in the traversal stack (>= tree depth, >= 1)
+    uint32_t stack_depth;      // depth of the tree (>= 1): the most entries a lane's traversal stack can hold
     uint32_t lean;             // 1: no cones and no polygon run with bounding records anywhere in the scene
     float bg[3];
 };

@@ -9,8 +9,8 @@
 // child is still unvisited has one stack entry {far child | axis << 30, plane}.  When a
 // subtree finishes with result r, entries are popped: the first one for which r is none or
 // beyond its plane discards r and descends into its far child; if none does, r is the
-// answer.  The per-lane stack lives in LDS (entry k of thread t at stack[k * blockDim.x + t]);
-// the host guarantees DevScene::stack_depth >= tree depth.
+// answer.  The per-lane stack lives in LDS (entry k of thread t at stack[k * blockDim.x + t]),
+// all of it for shallow trees, its newest entries for deep ones (KdStack).
 //
 // Leaves.  The reference walks a leaf's primitives in list order and keeps a hit when it is
 // strictly nearer than the best so far, so of equal distances the first in the list wins
@@ -424,13 +424,48 @@ RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, F3 
     if (q3.y) leaf_polygons<U, BND>(S, q3.x, q3.y, src, ray, un, ok_poly, near, ignore, lb, ctr);
 }
 
+// A lane's traversal stack.  RING false: entry k at lds[k * stride].  RING true: entries
+// [lo, sp) in the LDS slots k % RT_STACK_RING, entries [0, lo) in private memory; a push into a
+// full ring moves the oldest entry out first, a pop from an empty ring reads the entry back.
+template <bool RING>
+struct KdStack {
+    uint2* lds;
+    uint32_t stride, sp, lo;
+    uint2 deep[RING ? RT_STACK_DEEP : 1];
+    RT_DEV void init(uint2* lane_base, uint32_t lane_stride) { lds = lane_base; stride = lane_stride; sp = 0; lo = 0; }
+    RT_DEV bool empty() const { return sp == 0; }
+    RT_DEV void push(uint2 v) {
+        if constexpr (RING) {
+            if (sp - lo == RT_STACK_RING) {
+                deep[lo] = lds[(lo % RT_STACK_RING) * stride];
+                ++lo;
+            }
+            lds[(sp % RT_STACK_RING) * stride] = v;
+        } else {
+            lds[sp * stride] = v;
+        }
+        ++sp;
+    }
+    RT_DEV uint2 pop() {
+        --sp;
+        if constexpr (RING) {
+            if (sp < lo) {  // (then lo == sp + 1: the ring is empty)
+                lo = sp;
+                return deep[sp];
+            }
+            return lds[(sp % RT_STACK_RING) * stride];
+        } else {
+            return lds[sp * stride];
+        }
+    }
+};
+
 // Result of a finished subtree against the pending stack entries: returns true and sets
 // `cur` when some entry sends the walk into its far child, false when the walk is over.
-RT_DEV bool unwind(const uint2* my_stack, uint32_t stride, uint32_t& sp, F3 src, F3 ray, bool& r_hit, float r_dist,
-                   uint32_t& cur) {
-    while (sp > 0) {
-        --sp;
-        const uint2 ent = my_stack[sp * stride];
+template <bool RING>
+RT_DEV bool unwind(KdStack<RING>& st, F3 src, F3 ray, bool& r_hit, float r_dist, uint32_t& cur) {
+    while (!st.empty()) {
+        const uint2 ent = st.pop();
         const uint32_t axis = ent.x >> 30;
         const float plane = __uint_as_float(ent.y);
         bool take_second = !r_hit;
@@ -465,18 +500,19 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     }
     const float a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
     const uint32_t stride = blockDim.x;
-    uint2* my_stack = stack + threadIdx.x;
-    uint32_t* lane_words = (uint32_t*)(stack + S.stack_depth * stride) + threadIdx.x;  // RT_LANE_WORDS per lane, same stride
+    constexpr bool LEAN = (CULL & 4) != 0;
+    KdStack<!LEAN> st;
+    st.init(stack + threadIdx.x, stride);
+    // RT_LANE_WORDS per lane behind the stack's LDS entries, same stride
+    uint32_t* lane_words = (uint32_t*)(stack + (LEAN ? S.stack_depth : (uint32_t)RT_STACK_RING) * stride) + threadIdx.x;
     // The bounding-record tests assume that their intermediate values stay finite and normal,
     // and the one that looks behind the origin that hits before the origin do not count.
     constexpr int MODE = CULL & 3;
     const bool tame = a >= 1e-30f && a < 1e16f && dot(src, src) < 1e16f && (MODE != 2 || near >= 0.0f);
     F3 un = ray;
     if constexpr (MODE != 0) un = unit_ray(ray, a);
-    constexpr bool LEAN = (CULL & 4) != 0;
     constexpr int BND = LEAN ? 0 : MODE;  // (a lean scene has no cones and next to no polygons)
     const bool ok_cone = tame && near >= 0.0f;
-    uint32_t sp = 0;
     uint32_t cur = 0;
     bool done = false;
     bool r_hit = false;
@@ -513,13 +549,12 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                     ctr.interior_steps(1);
                     const float plane = __uint_as_float(q0.w);
                     const bool under_first = comp(src, axis) < plane;  // :303
-                    my_stack[sp * stride] = make_uint2((under_first ? q2.y : q2.x) | (axis << 30), q0.w);
-                    ++sp;
+                    st.push(make_uint2((under_first ? q2.y : q2.x) | (axis << 30), q0.w));
                     cur = under_first ? q2.x : q2.y;
                 }
             } else {
                 r_hit = false;
-                if (!unwind(my_stack, stride, sp, src, ray, r_hit, r.dist, cur)) done = true;
+                if (!unwind(st, src, ray, r_hit, r.dist, cur)) done = true;
             }
         }
 
@@ -589,7 +624,7 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                     r.n = lb.n;
                 }
             }
-            if (!unwind(my_stack, stride, sp, src, ray, r_hit, r.dist, cur)) done = true;
+            if (!unwind(st, src, ray, r_hit, r.dist, cur)) done = true;
         }
     }
     out = r;
