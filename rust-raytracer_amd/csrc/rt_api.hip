@@ -387,6 +387,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     RT_HIP(ctx, sc->bnd.upload(bnd));
     RT_HIP(ctx, sc->cone_items.upload(cone_items));
     RT_HIP(ctx, sc->poly_items.upload(poly_items));
+    // (the walks read these records eight at a time)
+    poly_bound.insert(poly_bound.end(), 8, make_float4(0.0f, 0.0f, 0.0f, INFINITY));
+    cone_bound.insert(cone_bound.end(), 8, make_float4(0.0f, 0.0f, 0.0f, INFINITY));
     RT_HIP(ctx, sc->poly_bound.upload(poly_bound));
     RT_HIP(ctx, sc->cone_bound.upload(cone_bound));
     RT_HIP(ctx, sc->vpos.upload(vpos));

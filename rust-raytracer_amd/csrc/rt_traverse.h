@@ -172,23 +172,20 @@ RT_DEV void leaf_spheres(const DevScene& S, uint32_t first, uint32_t count, F3 s
 
 template <bool BEHIND>
 RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 n);
+template <bool BEHIND, class Ctr>
+RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 n, Ctr& ctr);
 
 // BND: 0 = every entry gets the reference's test; 1 / 2 = a cylinder or polygon is first tried
 // through its own bounding record (cone_bound / poly_bound, the sphere its *_bound function in
 // leaf_cluster.cpp derives; 2 = also the behind-origin way out), `ok` saying whether this ray
 // may use the records (un = its unit direction).  The full tests cost 5 to 10 times a record's.
-template <bool U, int BND, class Ctr>
-RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, F3 un, bool ok, float near,
-                       uint32_t ignore, LeafBest& lb, Ctr& ctr) {
-    for (uint32_t k = 0; k < count; ++k) {
-        const uint4 it = ld_u4<U>(S.cone_items, first + k);  // {prim, list position, cone index, -}
-        if (it.x == ignore || (it.y >> 31) != 0u) continue;  // (bit 31: a padding copy of another entry)
-        if constexpr (BND != 0) {
-            if (ok) {
-                ctr.bound_tests(1);
-                if (!bound_may_hit<BND == 2>(ld_f4<U>(S.cone_bound, first + k), src, un)) continue;
-            }
-        }
+// A lane on its own (U false) tries the records eight at a time -- eight loads in flight instead
+// of one after the other, on walks that wait for memory -- and then visits the items left.
+template <bool U, class Ctr>
+RT_DEV void cone_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    {
+        const uint4 it = ld_u4<U>(S.cone_items, i);  // {prim, list position, cone index, -}
+        if (it.x == ignore || (it.y >> 31) != 0u) return;  // (bit 31: a padding copy of another entry)
         ctr.cone_tests(1);
         // {base, base radius} {w, axis length} {u, radius difference} {v, -}
         const float4 c0 = ld_f4<U>(S.cones, it.z * 4), c1 = ld_f4<U>(S.cones, it.z * 4 + 1),
@@ -209,26 +206,71 @@ RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src
 }
 
 template <bool U, int BND, class Ctr>
+RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, F3 un, bool ok, float near,
+                       uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    if constexpr (BND != 0 && !U) {
+        if (ok) {
+            for (uint32_t k0 = 0; k0 < count; k0 += 8u) {
+                uint32_t m = expand8<BND == 2>(S.cone_bound + first + k0, count - k0, src, un, ctr);
+                while (m != 0u) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    cone_item<false>(S, first + k0 + k, src, ray, near, ignore, lb, ctr);
+                }
+            }
+            return;
+        }
+    }
+    for (uint32_t k = 0; k < count; ++k) {
+        if constexpr (BND != 0) {
+            if (ok) {
+                ctr.bound_tests(1);
+                if (!bound_may_hit<BND == 2>(ld_f4<U>(S.cone_bound, first + k), src, un)) continue;
+            }
+        }
+        cone_item<U>(S, first + k, src, ray, near, ignore, lb, ctr);
+    }
+}
+
+template <bool U, class Ctr>
+RT_DEV void polygon_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    const uint4 it = ld_u4<U>(S.poly_items, i);  // {prim, list position, first vertex, n vertices}
+    if (it.x == ignore || (it.y >> 31) != 0u) return;  // (bit 31: a padding copy of another entry)
+    ctr.poly_tests(1);
+    float t;
+    F3 n;
+    if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, ld_f4<U>(S.poly_plane, i), src, ray, near, t, n, ctr)) {
+        ctr.poly_hits(1);
+        if (lb.better(t, it.y)) {
+            lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
+        }
+    }
+}
+
+template <bool U, int BND, class Ctr>
 RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, F3 un, bool ok, float near,
                           uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+    if constexpr (BND != 0 && !U) {
+        if (ok) {
+            for (uint32_t k0 = 0; k0 < count; k0 += 8u) {
+                uint32_t m = expand8<BND == 2>(S.poly_bound + first + k0, count - k0, src, un, ctr);
+                while (m != 0u) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    polygon_item<false>(S, first + k0 + k, src, ray, near, ignore, lb, ctr);
+                }
+            }
+            return;
+        }
+    }
     for (uint32_t k = 0; k < count; ++k) {
-        const uint4 it = ld_u4<U>(S.poly_items, first + k);  // {prim, list position, first vertex, n vertices}
-        if (it.x == ignore || (it.y >> 31) != 0u) continue;  // (bit 31: a padding copy of another entry)
         if constexpr (BND != 0) {
             if (ok) {
                 ctr.bound_tests(1);
                 if (!bound_may_hit<BND == 2>(ld_f4<U>(S.poly_bound, first + k), src, un)) continue;
             }
         }
-        ctr.poly_tests(1);
-        float t;
-        F3 n;
-        if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, ld_f4<U>(S.poly_plane, first + k), src, ray, near, t, n, ctr)) {
-            ctr.poly_hits(1);
-            if (lb.better(t, it.y)) {
-                lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
-            }
-        }
+        polygon_item<U>(S, first + k, src, ray, near, ignore, lb, ctr);
     }
 }
 
