@@ -30,6 +30,7 @@ struct DevScene {
     const uint4* poly_items;   // {primitive, position in the leaf's list, first vertex, vertex count}
     const float4* poly_plane;  // beside poly_items: {plane normal, edge-loop coordinates} (polygon_plane)
     const float4* poly_bound;  // beside poly_items: bounding record {C, q} of the polygon alone
+    const float4* poly_rect;   // beside poly_items: the polygon's extent in its edge-loop coordinates (polygon_rect)
     const float4* cone_bound;  // beside cone_items: the same for a cylinder; q = inf for a cone proper
     const float4* cones;       // 4 per cone: {base, base radius} {w, axis length} {u, radius difference} {v, -} (cone_frame)
     const float4* vpos;        // per vertex {point, 0}
@@ -101,7 +102,8 @@ struct DeinterleaveArgs {
     hipError_t launch_appraise(const float* boxes6, const uint32_t* list, uint32_t n, uint32_t axis, float* cost,    \
                                hipStream_t st);                                                                      \
     hipError_t launch_prepare_shapes(const float4* cones_in, uint32_t n_cones, float4* cones, const uint4* poly_items, \
-                                     uint32_t n_items, const float4* vpos, float4* poly_plane, hipStream_t st);      \
+                                     uint32_t n_items, const float4* vpos, float4* poly_plane, float4* poly_rect,    \
+                                     hipStream_t st);                                                                \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
     hipError_t launch_debug_intersect(const rtamd::DevScene& S, bool cull, uint64_t n, const float* src, const float* ray, \
                                       const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist, \

@@ -407,27 +407,55 @@ RT_DEV float4 polygon_plane(F3 v0, F3 v1, F3 v2) {  // {normal, minor | major <<
     return make_float4(gn.x, gn.y, gn.z, __uint_as_float(minor | (major << 2)));
 }
 
+//
+// `guard` = {minor lo, minor hi, major lo, major hi} lets the test stop before the edge loop,
+// which is most of its cost.  The loop accepts the point P = fl(src + ray t) of the plane only
+// if (a) some edge has 0 <= scale <= 1, scale = fl(fl(P.minor - next.minor) / edge.minor): then
+// fl(P.minor - next.minor) has edge.minor's sign and at most its size (1 + u), so P.minor lies in
+// that edge's minor range widened by 3u |edge.minor|; and (b) it finds a crossing at or beyond
+// P.major and one before it (:267-291: both or no hit), each crossing fl(fl(scale edge.major) +
+// next.major) lying in the edge's major range widened by 4u max|coordinate|.  polygon_rect
+// holds the polygon's two ranges widened by 1e-6 max|coordinate| (> 16u): a point outside them is
+// one the loop rejects.  Rays that graze a polygon's plane near the polygon meet the plane far
+// away and stop here.  {-inf, inf, -inf, inf} (no_guard) keeps the reference's full test; a NaN
+// coordinate of P passes the guard.
+RT_DEV float4 polygon_rect(const float4* __restrict__ vpos, uint32_t first, uint32_t n, float4 plane) {
+    const uint32_t minor = __float_as_uint(plane.w) & 3u, major = __float_as_uint(plane.w) >> 2;
+    float lo_m = INFINITY, hi_m = -INFINITY, lo_M = INFINITY, hi_M = -INFINITY, big_m = 0.0f, big_M = 0.0f;
+    bool bad = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const F3 v = from4(vpos[first + i]);
+        const float cm = comp(v, minor), cM = comp(v, major);
+        bad = bad || !(fabsf(cm) < 1e30f) || !(fabsf(cM) < 1e30f);
+        lo_m = fminf(lo_m, cm); hi_m = fmaxf(hi_m, cm); big_m = fmaxf(big_m, fabsf(cm));
+        lo_M = fminf(lo_M, cM); hi_M = fmaxf(hi_M, cM); big_M = fmaxf(big_M, fabsf(cM));
+    }
+    if (bad || n == 0u) return make_float4(-INFINITY, INFINITY, -INFINITY, INFINITY);
+    const float dm = fmaxf(big_m * 1e-6f, 1e-30f), dM = fmaxf(big_M * 1e-6f, 1e-30f);
+    return make_float4(lo_m - dm, hi_m + dm, lo_M - dM, hi_M + dM);
+}
+RT_DEV float4 no_guard() { return make_float4(-INFINITY, INFINITY, -INFINITY, INFINITY); }
 template <class Ctr>
 RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                         float4 plane, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr);
+                         float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr);
 template <class Ctr>
 RT_DEV_CALL ShapeHit polygon_call(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                                  float4 plane, F3 src, F3 ray, float near, Ctr& ctr) {
+                                  float4 plane, float4 guard, F3 src, F3 ray, float near, Ctr& ctr) {
     ShapeHit h;
     h.t = 0.0f; h.n = f3(0.0f, 0.0f, 0.0f);
-    h.ok = polygon_test(vpos, vnrm, first, n, plane, src, ray, near, h.t, h.n, ctr);
+    h.ok = polygon_test(vpos, vnrm, first, n, plane, guard, src, ray, near, h.t, h.n, ctr);
     return h;
 }
 template <class Ctr>
 RT_DEV bool isect_polygon(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                          float4 plane, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
-    const ShapeHit h = polygon_call(vpos, vnrm, first, n, plane, src, ray, near, ctr);
+                          float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
+    const ShapeHit h = polygon_call(vpos, vnrm, first, n, plane, guard, src, ray, near, ctr);
     t_out = h.t; n_out = h.n;
     return h.ok;
 }
 template <class Ctr>
 RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                         float4 plane, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
+                         float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
     const F3 v0 = from4(vpos[first]);
     const F3 gn = f3(plane.x, plane.y, plane.z);
     float den = dot(ray, gn);
@@ -439,6 +467,7 @@ RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restri
     F3 in_plane = add(src, mul(ray, plane_dist));
     const uint32_t minor = __float_as_uint(plane.w) & 3u, major = __float_as_uint(plane.w) >> 2;
     const float ip_minor = comp(in_plane, minor), ip_major = comp(in_plane, major);
+    if (ip_minor < guard.x || ip_minor > guard.y || ip_major < guard.z || ip_major > guard.w) return false;
 
     uint32_t count = 0;
     bool have_fwd = false, have_rev = false;

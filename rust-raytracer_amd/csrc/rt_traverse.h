@@ -232,14 +232,18 @@ RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src
     }
 }
 
-template <bool U, class Ctr>
+// GUARD: the test may stop before its edge loop when the plane is met outside the polygon's
+// extent (polygon_test; the exhaustive walk does not).
+template <bool U, bool GUARD, class Ctr>
 RT_DEV void polygon_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
     const uint4 it = ld_u4<U>(S.poly_items, i);  // {prim, list position, first vertex, n vertices}
     if (it.x == ignore || (it.y >> 31) != 0u) return;  // (bit 31: a padding copy of another entry)
     ctr.poly_tests(1);
     float t;
     F3 n;
-    if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, ld_f4<U>(S.poly_plane, i), src, ray, near, t, n, ctr)) {
+    float4 guard = no_guard();
+    if constexpr (GUARD) guard = ld_f4<U>(S.poly_rect, i);
+    if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, ld_f4<U>(S.poly_plane, i), guard, src, ray, near, t, n, ctr)) {
         ctr.poly_hits(1);
         if (lb.better(t, it.y)) {
             lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
@@ -257,7 +261,7 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
                 while (m != 0u) {
                     const uint32_t k = (uint32_t)__builtin_ctz(m);
                     m &= m - 1u;
-                    polygon_item<false>(S, first + k0 + k, src, ray, near, ignore, lb, ctr);
+                    polygon_item<false, true>(S, first + k0 + k, src, ray, near, ignore, lb, ctr);
                 }
             }
             return;
@@ -270,7 +274,7 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
                 if (!bound_may_hit<BND == 2>(ld_f4<U>(S.poly_bound, first + k), src, un)) continue;
             }
         }
-        polygon_item<U>(S, first + k, src, ray, near, ignore, lb, ctr);
+        polygon_item<U, BND != 0>(S, first + k, src, ray, near, ignore, lb, ctr);
     }
 }
 

@@ -72,7 +72,7 @@ def test_cylinder_stand_in_sphere_holds_every_accepted_point(oracle):
 
 def test_polygon_stand_in_sphere_holds_every_accepted_point(oracle):
     rng = np.random.default_rng(6)
-    worst, accepted = 0.0, 0
+    worst, accepted, worst_guard = 0.0, 0, 0.0
     for k in range(200):
         nv = 3 if k % 3 else 4
         size = 10.0 ** rng.uniform(-2, 1)
@@ -105,8 +105,30 @@ def test_polygon_stand_in_sphere_holds_every_accepted_point(oracle):
             over = np.linalg.norm(x[hit] - c, axis=1) - (r + 1.1e-5 * e)
             worst = max(worst, float((over / (r + 1.1e-5 * e)).max()))
             accepted += int(hit.sum())
+            # the guard in front of the device's edge loop (rt_shapes.h polygon_rect / polygon_test):
+            # the point the reference goes on with, fl(src + fl(ray t)) in f32, lies in the polygon's
+            # extent on the two coordinates the edge loop works in, widened by 1e-6 max|coordinate|
+            _, dist, _ = oracle.shape_batch(KIND_POLYGON, None, verts6, src, ray, near)
+            p32 = (src + ray * dist.astype(np.float32)[:, None]).astype(np.float32)[hit]
+            ea, eb = v[1] - v[0], v[2] - v[0]  # f32, as polygon_plane forms the normal
+            gn = np.array([ea[1] * eb[2] - ea[2] * eb[1], ea[2] * eb[0] - ea[0] * eb[2], ea[0] * eb[1] - ea[1] * eb[0]], np.float32)
+            if abs(gn[2]) > abs(gn[0]) and abs(gn[2]) > abs(gn[1]):
+                kept = (1, 0)
+            elif abs(gn[1]) > abs(gn[0]):
+                kept = (2, 0)
+            else:
+                kept = (2, 1)
+            for ax in kept:
+                widen = np.float32(max(np.abs(v[:, ax]).max() * np.float32(1e-6), 1e-30))
+                lo, hi = v[:, ax].min() - widen, v[:, ax].max() + widen
+                assert (p32[:, ax] >= lo).all() and (p32[:, ax] <= hi).all()
+                inner = (hi - lo) - 2 * widen
+                if inner > 0:  # how far into the widening accepted points reach (1 = its edge)
+                    reach = np.maximum(lo + widen - p32[:, ax], p32[:, ax] - (hi - widen)) / widen
+                    worst_guard = max(worst_guard, float(reach.max()))
     assert accepted > 20000
     assert worst <= 0.0, worst
+    assert worst_guard < 0.5, worst_guard
 
 
 def test_sphere_acceptance_margin_of_the_bounding_records(oracle):
