@@ -12,6 +12,11 @@
 #include "rt_host.h"
 #include "rt_launch.h"
 
+// Polygon and cylinder runs of at least this many entries get a hierarchy of bounding records.
+#ifndef RT_HIER_MIN
+#define RT_HIER_MIN 12
+#endif
+
 using namespace rtamd;
 
 namespace {
@@ -327,7 +332,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         }
         // polygon runs worth a hierarchy get one over the spheres that stand in for the polygons
         uint32_t pu0 = 0xffffffffu;
-        if (poly_bounds && lp.size() >= 12) {
+        if (poly_bounds && lp.size() >= RT_HIER_MIN) {
             pu0 = cluster_spheres(lp, bnd);
             any_poly_walk = true;
         }
@@ -338,7 +343,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         // Cone items: the cylinders first (under a hierarchy of their own when there are enough of
         // them), then the cones proper, which no sphere can stand in for.
         uint32_t cu0 = 0xffffffffu;
-        if (lc.size() >= 12) {
+        if (lc.size() >= RT_HIER_MIN) {
             cu0 = cluster_spheres(lc, bnd);
         }
         const uint32_t c0 = (uint32_t)cone_items.size() + (cu0 != 0xffffffffu ? (uint32_t)lc.size() : 0u);

@@ -121,10 +121,19 @@ RT_DEV bool sphere_quick(float cx, float cy, float cz, float rr, F3 src, F3 ray,
     return d * d >= a * c;
 }
 
-template <bool U, class Ctr>
+template <class Ctr>
+RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, float near, uint32_t ignore, LeafBest& lb,
+                     Ctr& ctr);
+
+// BATCH (lanes on their own, U false): eight entries per step, their loads in flight together
+// (runs are padded to a multiple of 8 entries); otherwise entry by entry, which is what the
+// counters of the reference's own work need.
+template <bool U, bool BATCH, class Ctr>
 RT_DEV void leaf_spheres(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, float a, float near,
                          uint32_t ignore, LeafBest& lb, Ctr& ctr) {
-    if constexpr (U) {
+    if constexpr (!U && BATCH) {
+        for (uint32_t k0 = 0; k0 < count; k0 += 8u) cluster8(S, first + k0, src, ray, a, near, ignore, lb, ctr);
+    } else if constexpr (U) {
         // Wave-uniform walk, four spheres (one 64-byte scalar load) per step; the next step's
         // load is issued before this step's arithmetic so that its latency is covered.
         typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -300,7 +309,10 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
 // ---------------------------------------------------------------------------------------
 constexpr float CULL_ONE_MINUS_BETA = 0.999978f;  // 1 - 2.2e-5
 constexpr float CULL_BETA = 2.2e-5f;
-constexpr uint32_t CULL_MIN_SPHERES = 24;         // shorter runs are walked entry by entry
+#ifndef RT_CULL_MIN_SPHERES
+#define RT_CULL_MIN_SPHERES 24
+#endif
+constexpr uint32_t CULL_MIN_SPHERES = RT_CULL_MIN_SPHERES;  // shorter runs are walked eight entries at a time
 constexpr uint32_t LANE_STACK = 4;                   // per-lane LDS words: 4 stack entries, then the queue
 constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - LANE_STACK;
 
@@ -462,10 +474,10 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
     drain();
 }
 
-template <bool U, int BND, class Ctr>
+template <bool U, int BND, bool BATCH, class Ctr>
 RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, F3 un, bool ok_cone, bool ok_poly, float a,
                       float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
-    if (q2.y) leaf_spheres<U>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
+    if (q2.y) leaf_spheres<U, BATCH>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
     if (q2.w) leaf_cones<U, BND>(S, q2.z, q2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
     if (q3.y) leaf_polygons<U, BND>(S, q3.x, q3.y, src, ray, un, ok_poly, near, ignore, lb, ctr);
 }
@@ -648,16 +660,16 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                         const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y),
                                                     0u, 0u);
                         if constexpr (MODE != 0) leaf_cones<true, BND>(S, u2.z, u2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
-                        else leaf_runs<true, 0>(S, u2, u3, src, ray, un, false, false, a, near, ignore, lb, ctr);
+                        else leaf_runs<true, 0, false>(S, u2, u3, src, ray, un, false, false, a, near, ignore, lb, ctr);
                         mine_done = true;
                     }
                 }
                 if constexpr (MODE != 0) {
                     q2.w = 0u;
-                    leaf_runs<false, BND>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
+                    leaf_runs<false, BND, MODE != 0>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
                 }
             } else {
-                leaf_runs<false, BND>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
+                leaf_runs<false, BND, MODE != 0>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
             }
             r_hit = lb.have;
             if (lb.have) {
