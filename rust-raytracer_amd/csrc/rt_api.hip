@@ -105,7 +105,7 @@ struct rt_scene {
     DevBuf<float4> sph;
     DevBuf<uint2> sph_id;
     DevBuf<float> bnd;
-    DevBuf<float4> cones, poly_plane, poly_rect, poly_bound, cone_bound, vpos, vnrm, surfaces, lights;
+    DevBuf<float4> cones, poly_rec, poly_bound, cone_bound, vpos, vnrm, surfaces, lights;
     DevBuf<uint32_t> prim_surface;
     DevScene dev{};
 };
@@ -404,10 +404,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         DevBuf<float4> cones_in;
         RT_HIP(ctx, cones_in.upload(cones));
         RT_HIP(ctx, sc->cones.alloc(sd.cones.size() * 4));
-        RT_HIP(ctx, sc->poly_plane.alloc(poly_items.size()));
-        RT_HIP(ctx, sc->poly_rect.alloc(poly_items.size()));
+        RT_HIP(ctx, sc->poly_rec.alloc(poly_items.size() * 4));
         RT_HIP(ctx, rt_exact::launch_prepare_shapes(cones_in.p, (uint32_t)sd.cones.size(), sc->cones.p, sc->poly_items.p,
-                                                    (uint32_t)poly_items.size(), sc->vpos.p, sc->poly_plane.p, sc->poly_rect.p,
+                                                    (uint32_t)poly_items.size(), sc->vpos.p, sc->poly_rec.p,
                                                     nullptr));
         RT_HIP(ctx, hipStreamSynchronize(nullptr));
     }
@@ -422,10 +421,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.sph_id = sc->sph_id.p;
     d.bnd = (const float4*)sc->bnd.p;
     d.cone_items = sc->cone_items.p;
-    d.poly_items = sc->poly_items.p;
-    d.poly_plane = sc->poly_plane.p;
+    d.poly_rec = sc->poly_rec.p;
     d.poly_bound = sc->poly_bound.p;
-    d.poly_rect = sc->poly_rect.p;
     d.cone_bound = sc->cone_bound.p;
     d.cones = sc->cones.p;
     d.vpos = sc->vpos.p;

@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_appraise(const float* __restrict__
 // difference} {v, -}), then one per polygon entry of the leaf runs (-> polygon_plane).
 __global__ void __launch_bounds__(RT_BLOCK) k_prepare_shapes(const float4* cones_in, uint32_t n_cones, float4* cones,
                                                              const uint4* poly_items, uint32_t n_items, const float4* vpos,
-                                                             float4* poly_plane, float4* poly_rect) {
+                                                             float4* poly_rec) {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i < n_cones) {
         const float4 b = cones_in[i * 2], a = cones_in[i * 2 + 1];
@@ -452,10 +452,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_prepare_shapes(const float4* cones
         cones[i * 4 + 3] = make_float4(f.v.x, f.v.y, f.v.z, 0.0f);
     } else if (i - n_cones < n_items) {
         const uint32_t k = i - n_cones;
-        const uint32_t first = poly_items[k].z;
+        const uint4 it = poly_items[k];
+        const uint32_t first = it.z;
         const float4 plane = polygon_plane(from4(vpos[first]), from4(vpos[first + 1]), from4(vpos[first + 2]));
-        poly_plane[k] = plane;
-        poly_rect[k] = polygon_rect(vpos, first, poly_items[k].w, plane);
+        poly_rec[k * 4 + 0] = make_float4(__uint_as_float(it.x), __uint_as_float(it.y), __uint_as_float(it.z), __uint_as_float(it.w));
+        poly_rec[k * 4 + 1] = plane;
+        poly_rec[k * 4 + 2] = polygon_rect(vpos, first, it.w, plane);
+        poly_rec[k * 4 + 3] = vpos[first];
     }
 }
 
@@ -539,8 +542,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
             break;
         }
         case 3:  // RT_OP_POLYGON
-            ok = isect_polygon(vpos, vnrm, 0u, n_verts, polygon_plane(from4(vpos[0]), from4(vpos[1]), from4(vpos[2])),
-                               no_guard(), f3(a[0], a[1], a[2]), f3(a[3], a[4], a[5]), a[6], t, nn, ctr);
+            ok = isect_polygon(vpos, vnrm, 0u, n_verts, from4(vpos[0]),
+                               polygon_plane(from4(vpos[0]), from4(vpos[1]), from4(vpos[2])), no_guard(), f3(a[0], a[1], a[2]), f3(a[3], a[4], a[5]), a[6], t, nn, ctr);
             break;
         case 4:
         case 5: {  // RT_OP_PHONG / RT_OP_BLINN: surface9, n, v, l, lc
@@ -667,12 +670,11 @@ hipError_t launch_appraise(const float* boxes6, const uint32_t* list, uint32_t n
 }
 
 hipError_t launch_prepare_shapes(const float4* cones_in, uint32_t n_cones, float4* cones, const uint4* poly_items,
-                                 uint32_t n_items, const float4* vpos, float4* poly_plane, float4* poly_rect,
-                                 hipStream_t st) {
+                                 uint32_t n_items, const float4* vpos, float4* poly_rec, hipStream_t st) {
     const uint64_t n = (uint64_t)n_cones + n_items;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_prepare_shapes, dim3((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, st, cones_in,
-                       n_cones, cones, poly_items, n_items, vpos, poly_plane, poly_rect);
+                       n_cones, cones, poly_items, n_items, vpos, poly_rec);
     return hipGetLastError();
 }
 

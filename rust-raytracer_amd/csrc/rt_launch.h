@@ -27,10 +27,11 @@ struct DevScene {
     const uint2* sph_id;       // parallel to sph: {primitive, position in the leaf's list}
     const float4* bnd;         // per sphere run: header + bounding records {centre, q}, 8-ary, up to 4 levels
     const uint4* cone_items;   // {primitive, position in the leaf's list, cone index, -}
-    const uint4* poly_items;   // {primitive, position in the leaf's list, first vertex, vertex count}
-    const float4* poly_plane;  // beside poly_items: {plane normal, edge-loop coordinates} (polygon_plane)
-    const float4* poly_bound;  // beside poly_items: bounding record {C, q} of the polygon alone
-    const float4* poly_rect;   // beside poly_items: the polygon's extent in its edge-loop coordinates (polygon_rect)
+    // polygon runs, 64 bytes (one cache line, one round trip) per entry: {primitive, position in the
+    // leaf's list, first vertex, vertex count} {plane normal, edge-loop coordinates} (polygon_plane)
+    // {extent in the edge-loop coordinates} (polygon_rect) {first vertex's point, -}
+    const float4* poly_rec;
+    const float4* poly_bound;  // beside poly_rec: bounding record {C, q} of the polygon alone
     const float4* cone_bound;  // beside cone_items: the same for a cylinder; q = inf for a cone proper
     const float4* cones;       // 4 per cone: {base, base radius} {w, axis length} {u, radius difference} {v, -} (cone_frame)
     const float4* vpos;        // per vertex {point, 0}
@@ -102,7 +103,7 @@ struct DeinterleaveArgs {
     hipError_t launch_appraise(const float* boxes6, const uint32_t* list, uint32_t n, uint32_t axis, float* cost,    \
                                hipStream_t st);                                                                      \
     hipError_t launch_prepare_shapes(const float4* cones_in, uint32_t n_cones, float4* cones, const uint4* poly_items, \
-                                     uint32_t n_items, const float4* vpos, float4* poly_plane, float4* poly_rect,    \
+                                     uint32_t n_items, const float4* vpos, float4* poly_rec,                        \
                                      hipStream_t st);                                                                \
     hipError_t launch_deinterleave(const rtamd::DeinterleaveArgs& D, hipStream_t st);                                \
     hipError_t launch_debug_intersect(const rtamd::DevScene& S, bool cull, uint64_t n, const float* src, const float* ray, \

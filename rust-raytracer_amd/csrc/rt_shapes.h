@@ -437,26 +437,25 @@ RT_DEV float4 polygon_rect(const float4* __restrict__ vpos, uint32_t first, uint
 RT_DEV float4 no_guard() { return make_float4(-INFINITY, INFINITY, -INFINITY, INFINITY); }
 template <class Ctr>
 RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                         float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr);
+                         F3 v0, float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr);
 template <class Ctr>
 RT_DEV_CALL ShapeHit polygon_call(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                                  float4 plane, float4 guard, F3 src, F3 ray, float near, Ctr& ctr) {
+                                  F3 v0, float4 plane, float4 guard, F3 src, F3 ray, float near, Ctr& ctr) {
     ShapeHit h;
     h.t = 0.0f; h.n = f3(0.0f, 0.0f, 0.0f);
-    h.ok = polygon_test(vpos, vnrm, first, n, plane, guard, src, ray, near, h.t, h.n, ctr);
+    h.ok = polygon_test(vpos, vnrm, first, n, v0, plane, guard, src, ray, near, h.t, h.n, ctr);
     return h;
 }
 template <class Ctr>
 RT_DEV bool isect_polygon(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                          float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
-    const ShapeHit h = polygon_call(vpos, vnrm, first, n, plane, guard, src, ray, near, ctr);
+                          F3 v0, float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
+    const ShapeHit h = polygon_call(vpos, vnrm, first, n, v0, plane, guard, src, ray, near, ctr);
     t_out = h.t; n_out = h.n;
     return h.ok;
 }
 template <class Ctr>
 RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
-                         float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
-    const F3 v0 = from4(vpos[first]);
+                         F3 v0, float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
     const F3 gn = f3(plane.x, plane.y, plane.z);
     float den = dot(ray, gn);
     if (fabsf(den) < 0.000001f) return false;

@@ -245,14 +245,16 @@ RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src
 // extent (polygon_test; the exhaustive walk does not).
 template <bool U, bool GUARD, class Ctr>
 RT_DEV void polygon_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
-    const uint4 it = ld_u4<U>(S.poly_items, i);  // {prim, list position, first vertex, n vertices}
+    // {prim, list position, first vertex, n vertices} {plane} {extent} {first vertex}: one cache line
+    const float4 r0 = ld_f4<U>(S.poly_rec, i * 4u), plane = ld_f4<U>(S.poly_rec, i * 4u + 1u),
+                 rect = ld_f4<U>(S.poly_rec, i * 4u + 2u), p0 = ld_f4<U>(S.poly_rec, i * 4u + 3u);
+    const uint4 it = make_uint4(__float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z), __float_as_uint(r0.w));
     if (it.x == ignore || (it.y >> 31) != 0u) return;  // (bit 31: a padding copy of another entry)
     ctr.poly_tests(1);
     float t;
     F3 n;
-    float4 guard = no_guard();
-    if constexpr (GUARD) guard = ld_f4<U>(S.poly_rect, i);
-    if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, ld_f4<U>(S.poly_plane, i), guard, src, ray, near, t, n, ctr)) {
+    const float4 guard = GUARD ? rect : no_guard();
+    if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, from4(p0), plane, guard, src, ray, near, t, n, ctr)) {
         ctr.poly_hits(1);
         if (lb.better(t, it.y)) {
             lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
