@@ -365,7 +365,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;
-    for (const rt_cone& c : sd.cones) {
+    // (one frame per cone ENTRY, beside cone_items: an entry's loads do not wait for its item)
+    for (const uint4& it : cone_items) {
+        const rt_cone& c = sd.cones[it.z];
         cones.push_back(f4(c.base, c.base_radius));
         cones.push_back(f4(c.apex, c.apex_radius));
     }
@@ -403,9 +405,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         // (the exact build's: no contraction, correctly rounded divide and square root).
         DevBuf<float4> cones_in;
         RT_HIP(ctx, cones_in.upload(cones));
-        RT_HIP(ctx, sc->cones.alloc(sd.cones.size() * 4));
+        RT_HIP(ctx, sc->cones.alloc(cone_items.size() * 4));
         RT_HIP(ctx, sc->poly_rec.alloc(poly_items.size() * 4));
-        RT_HIP(ctx, rt_exact::launch_prepare_shapes(cones_in.p, (uint32_t)sd.cones.size(), sc->cones.p, sc->poly_items.p,
+        RT_HIP(ctx, rt_exact::launch_prepare_shapes(cones_in.p, (uint32_t)cone_items.size(), sc->cones.p, sc->poly_items.p,
                                                     (uint32_t)poly_items.size(), sc->vpos.p, sc->poly_rec.p,
                                                     nullptr));
         RT_HIP(ctx, hipStreamSynchronize(nullptr));

@@ -33,7 +33,7 @@ struct DevScene {
     const float4* poly_rec;
     const float4* poly_bound;  // beside poly_rec: bounding record {C, q} of the polygon alone
     const float4* cone_bound;  // beside cone_items: the same for a cylinder; q = inf for a cone proper
-    const float4* cones;       // 4 per cone: {base, base radius} {w, axis length} {u, radius difference} {v, -} (cone_frame)
+    const float4* cones;       // 4 per entry of cone_items: {base, base radius} {w, axis length} {u, radius difference} {v, -} (cone_frame)
     const float4* vpos;        // per vertex {point, 0}
     const float4* vnrm;        // per vertex {normal, 0}
     const float4* surfaces;    // 3 per surface: {color, kd} {ks, shine, reflectance, transmittance} {ior, model bits, -, -}

@@ -194,11 +194,12 @@ template <bool U, class Ctr>
 RT_DEV void cone_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
     {
         const uint4 it = ld_u4<U>(S.cone_items, i);  // {prim, list position, cone index, -}
+        // {base, base radius} {w, axis length} {u, radius difference} {v, -}, stored per entry: these
+        // loads leave together with the item's
+        const float4 c0 = ld_f4<U>(S.cones, i * 4u), c1 = ld_f4<U>(S.cones, i * 4u + 1u),
+                     c2 = ld_f4<U>(S.cones, i * 4u + 2u), c3 = ld_f4<U>(S.cones, i * 4u + 3u);
         if (it.x == ignore || (it.y >> 31) != 0u) return;  // (bit 31: a padding copy of another entry)
         ctr.cone_tests(1);
-        // {base, base radius} {w, axis length} {u, radius difference} {v, -}
-        const float4 c0 = ld_f4<U>(S.cones, it.z * 4), c1 = ld_f4<U>(S.cones, it.z * 4 + 1),
-                     c2 = ld_f4<U>(S.cones, it.z * 4 + 2), c3 = ld_f4<U>(S.cones, it.z * 4 + 3);
         ConeFrame fr;
         fr.w = f3(c1.x, c1.y, c1.z); fr.mag = c1.w;
         fr.u = f3(c2.x, c2.y, c2.z); fr.dr = c2.w;
