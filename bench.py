@@ -97,7 +97,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--fp", choices=["exact", "fast"], default="exact")
-    ap.add_argument("--cpu-rows", type=int, default=8, help="rows of the frame the CPU baseline renders per leg")
+    ap.add_argument("--cpu-rows", type=int, default=32, help="rows of the frame the CPU baseline renders per leg")
     ap.add_argument("--lights", type=int, default=0, help="mount only: number of point lights")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
