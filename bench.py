@@ -12,8 +12,9 @@ grows (strong scaling).  Scene parse, tree build and upload happen before the ti
 region; inputs are resident in HBM when it starts and the finished image stays in HBM.
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline      VALU roofline of the trace kernels (this path has no dense contraction
-                and its scene data is cache resident, so neither "mfma" nor "hbm" binds):
+  roofline      vector-ALU roofline of the trace kernels (this path has no dense contraction
+                and its scene data is cache resident, so neither "mfma" nor "hbm" binds; what
+                does is vector issue with few waves ready per SIMD, i.e. memory latency):
                 FLOPs the kernels execute per frame (device work counters of one
                 instrumented frame x per-event coefficients) / summed trace-kernel time per
                 frame (HIP events on the launch stream), against the 157.3 TFLOP/s f32
@@ -67,10 +68,12 @@ FRAMEBUFFER_BYTES = 3      # u8 RGB per pixel
 FLOP_SAVED = {"cone_tests": 42, "poly_tests": 18}
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-# Plain (not packed, not fused) f32 vector instructions issue one wave64 instruction per SIMD every
-# 4 cycles: 256 CUs x 64 lanes x 2.4 GHz lane-operations per second.  The parity mode may neither
-# fuse nor pack the reference's arithmetic, so this is the ceiling its counted operations can reach.
-PEAK_PLAIN_TOPS = 39.3
+# Plain (not fused) f32 vector instructions: a gfx950 SIMD is 32 lanes wide, a wave64 instruction
+# occupies it for 2 cycles: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz lane-operations per second, reached
+# only with several waves issuing per SIMD (tools/micro/pk_rate.hip measures 28 / 51 / 56 / 65 T with
+# 1 / 2 / 4 / 8 waves; packed instructions take twice as long).  The parity mode may not fuse the
+# reference's arithmetic, so this is the ceiling its counted operations can reach.
+PEAK_PLAIN_TOPS = 78.6
 
 
 def measured_traffic(args):
