@@ -127,9 +127,10 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
 
 
 def polygon_cloud(rng, n, scale, offset):
-    """A floor (which keeps the reference's builder from splitting) over a cloud of triangles
-    and quads: ordinary ones, slivers whose first three vertices are nearly collinear (their
-    plane normal is rounding noise), axis-aligned ones, and non-planar quads."""
+    """A floor (which keeps the reference's builder from splitting) over a cloud of polygons:
+    ordinary triangles, slivers whose first three vertices are nearly collinear (their plane
+    normal is rounding noise), axis-aligned ones, non-planar quads, hexagons of six arbitrary
+    vertices and planar pentagons that are not convex."""
     lines = ["v", "from %g %g %g" % tuple(offset + scale * np.array([3.0, 3.0, 2.0])), "at %g %g %g" % tuple(offset),
              "up 0 0 1", "angle 40", "hither %g" % (scale * 1e-3), "resolution 32 32", "l %g %g %g" % tuple(offset + 5 * scale),
              "f 1 0.5 0.5 0.5 0.5 3 0 0", "p 4"]
@@ -139,9 +140,15 @@ def polygon_cloud(rng, n, scale, offset):
     for k in range(n):
         c = offset + rng.uniform(-1, 1, 3) * scale
         size = scale * 10.0 ** rng.uniform(-2.5, -0.7)
-        kind = k % 5
-        nv = 4 if kind == 4 else 3
-        v = c + rng.normal(size=(nv, 3)) * size
+        kind = k % 7
+        nv = {4: 4, 5: 6, 6: 5}.get(kind, 3)
+        v = c + rng.normal(size=(nv, 3)) * size  # (kind 5: six arbitrary vertices -- not planar, edges may cross)
+        if kind == 6:    # planar and not convex: every other vertex pulled towards the centre
+            e1 = rng.normal(size=3); e1 /= np.linalg.norm(e1)
+            e2 = np.cross(e1, rng.normal(size=3)); e2 /= np.linalg.norm(e2)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, nv))
+            rad = size * np.where(np.arange(nv) % 2 == 0, 1.0, rng.uniform(0.15, 0.5))
+            v = c + (np.cos(ang) * rad)[:, None] * e1 + (np.sin(ang) * rad)[:, None] * e2
         if kind == 1:    # sliver: the third vertex almost on the line through the first two
             v[2] = v[0] + (v[1] - v[0]) * rng.uniform(0.2, 0.8) + rng.normal(size=3) * size * 1e-6
         elif kind == 2:  # axis-aligned
