@@ -70,6 +70,78 @@ def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, heig
     return st, fst
 
 
+def random_scene(seed, size=96):
+    """Spheres, cylinders, cones, flat polygons of 3 to 7 vertices (some not convex) and patches
+    with their own normals, scattered so that the reference's builder makes a real tree; two or
+    three lights, some mirrors, some glass."""
+    rng = np.random.default_rng(seed)
+    lines = ["v", "from 4.2 3.1 2.6", "at 0 0 0.2", "up 0 0 1", "angle 38", "hither 0.05", "resolution %d %d" % (size, size),
+             "b 0.1 0.2 0.35"]
+    for _ in range(int(rng.integers(2, 4))):
+        p = rng.uniform(-6, 6, 3)
+        p[2] = rng.uniform(4, 9)
+        lines.append("l %.6g %.6g %.6g %.3g %.3g %.3g" % (*p, *rng.uniform(0.3, 0.7, 3)))
+
+    def surface():
+        kind = rng.integers(0, 4)
+        ks = (0.0, 0.4, 0.6, 0.1)[kind]
+        t = 0.8 if kind == 3 else 0.0
+        lines.append("f %.3g %.3g %.3g %.3g %.3g %.3g %.3g %.3g" % (*rng.uniform(0.2, 1.0, 3), 1.0 - ks, ks,
+                                                                      rng.choice([1.0, 4.0, 30.0]), t, 1.5 if t else 0.0))
+
+    surface()
+    for gx in range(-3, 3):  # a floor in tiles (one polygon across the scene keeps the builder from splitting)
+        for gy in range(-3, 3):
+            lines += ["p 4", "%d %d -0.6" % (gx, gy), "%d %d -0.6" % (gx + 1, gy), "%d %d -0.6" % (gx + 1, gy + 1),
+                      "%d %d -0.6" % (gx, gy + 1)]
+    for _ in range(int(rng.integers(30, 160))):
+        if rng.random() < 0.15:
+            surface()
+        c = rng.uniform(-1.6, 1.6, 3)
+        s = 10.0 ** rng.uniform(-1.4, -0.5)
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            lines.append("s %.7g %.7g %.7g %.7g" % (*c, s))
+        elif kind == 1:  # cylinder or cone
+            a = c + rng.normal(size=3) * s * 2
+            r0 = s * rng.uniform(0.2, 0.8)
+            r1 = r0 if rng.random() < 0.7 else r0 * rng.uniform(0.0, 0.9)
+            lines += ["c", "%.7g %.7g %.7g %.7g" % (*c, r0), "%.7g %.7g %.7g %.7g" % (*a, r1)]
+        else:
+            nv = int(rng.integers(3, 8))
+            e1 = rng.normal(size=3); e1 /= np.linalg.norm(e1)
+            e2 = np.cross(e1, rng.normal(size=3)); e2 /= np.linalg.norm(e2)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, nv))
+            rad = s * rng.uniform(0.3, 1.0, nv)  # (uneven radii: often not convex)
+            v = c + (np.cos(ang) * rad)[:, None] * e1 + (np.sin(ang) * rad)[:, None] * e2
+            if kind == 5:  # patch: normals near the plane's, one per vertex
+                n0 = np.cross(e1, e2)
+                lines.append("pp %d" % nv)
+                for q in v:
+                    n = n0 + rng.normal(size=3) * 0.3
+                    lines.append("%.7g %.7g %.7g %.5g %.5g %.5g" % (*q, *n))
+            else:
+                lines.append("p %d" % nv)
+                for q in v:
+                    lines.append("%.7g %.7g %.7g" % tuple(q))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTAMD_FUZZ_SEEDS", "16"))))  # (more seeds for a longer soak)
+def test_random_mixed_scenes(rtamd, oracle, gpu_ctx, seed):
+    """Scenes nobody arranged: every primitive kind in one tree, shadows, mirrors and glass.  Exact
+    mode, culled and exhaustive, equals the oracle bit for bit (fast mode is not held to a bar
+    here: mirror chains between small curved mirrors)."""
+    text = random_scene(seed)
+    try:
+        o = oracle.OracleScene(text)
+    except Exception as e:  # a scene on which the reference's builder does not terminate
+        pytest.skip(str(e))
+    assert o.info.nodes > 9
+    check_scene(rtamd, oracle, gpu_ctx, text, depth=6, fast_bar=1.0)
+    check_scene(rtamd, oracle, gpu_ctx, text, phong=False, depth=2, work=False, fast_bar=1.0)
+
+
 @pytest.mark.parametrize("name", REFERENCE_FIXTURES + EXTRA)
 def test_fixture_scenes(rtamd, oracle, gpu_ctx, name):
     check_scene(rtamd, oracle, gpu_ctx, read_nff(name))
