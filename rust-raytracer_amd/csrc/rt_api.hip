@@ -558,6 +558,29 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.overflow = f.levels.p + LV_OVERFLOW;
     A.counters = f.counters.p;
 
+    // Levels that cannot hold a ray are not launched.  A ray of level k carries a contribution of
+    // at most w^k, w the largest reflectance in the scene, when nothing transmits (a surface with
+    // transmittance above the cutoff passes rays on at weight 1 from its back, src/scene.rs:151-165,
+    // so then there is no bound); level k + 1 needs contribution * weight > min_contribution
+    // (src/scene.rs:127-130, :166-167).  The bound is taken with room for the f32 products' rounding.
+    uint32_t last_level = opt->max_depth;
+    if (opt->min_contribution >= 0.0f) {
+        double w = 0.0;
+        bool bounded = true;
+        for (const rt_surface& sf : scene->data.surfaces) {
+            if (!(sf.reflectance >= 0.0f) || !(sf.reflectance < 1e30f) || !(sf.transmittance <= opt->min_contribution)) bounded = false;
+            w = std::max(w, (double)sf.reflectance * (1.0 + 1e-6));
+        }
+        if (bounded) {
+            uint32_t k = 0;
+            double c = 1.0;  // bound on a level-k ray's contribution
+            while (k < opt->max_depth && c * w > (double)opt->min_contribution) {
+                c *= w;
+                ++k;
+            }
+            last_level = k;
+        }
+    }
     const bool fast = opt->fp_mode == RT_FP_FAST;
     const bool work = opt->collect_work != 0;
     const bool cull = opt->exhaustive_leaves == 0;
@@ -581,12 +604,12 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
                          : rt_exact::launch_light(A, first, last, work, gl, st2));
         return RT_OK;
     };
-    for (uint32_t level = 0; level <= opt->max_depth; ++level) {
+    for (uint32_t level = 0; level <= last_level; ++level) {
         const uint32_t g = level == 0 ? grid0 : gridn;
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
         if (n_lights) {  // this level's shadow rays and lighting: beside the next levels, on the second stream
             RT_HIP(ctx, hipEventRecord(f.ev_level[level], st));
-            if (level < SHADOW_GROUP_FROM || level == opt->max_depth) {
+            if (level < SHADOW_GROUP_FROM || level == last_level) {
                 const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
                 rc = shadow_and_light(first, level);
                 if (rc != RT_OK) return rc;
@@ -598,7 +621,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_shadow, 0));
     }
     RT_HIP(ctx, hipEventRecord(f.ev[1], st));
-    for (uint32_t level = opt->max_depth + 1; level-- > 0;) {
+    for (uint32_t level = last_level + 1; level-- > 0;) {
         const uint32_t g = level == 0 ? grid0 : gridn;
         if (level == 0) RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_caller, 0));  // the caller's buffers are written from here on
         RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));

@@ -196,6 +196,27 @@ def test_depth_zero_and_deep(rtamd, oracle, gpu_ctx):
         check_scene(rtamd, oracle, gpu_ctx, text, depth=depth, width=96, height=64, work=False)
 
 
+@pytest.mark.parametrize("ks,cutoff,deepest", [(0.05, 0.003, 1), (0.5, 0.2, 2), (0.5, 0.003, 6), (0.0, 0.003, 0), (0.9, 0.0, 6)])
+def test_levels_that_cannot_hold_rays(rtamd, oracle, gpu_ctx, ks, cutoff, deepest):
+    """The library does not launch bounce levels that the surfaces' reflectances and the
+    contribution cutoff rule out (no transmitting surface here): images and ray counts must
+    still be the oracle's, for weights and cutoffs on either side of the bound, and the
+    deepest level that holds rays is the expected one."""
+    text = ("v\nfrom 0 -4 1\nat 0 0 0.4\nup 0 0 1\nangle 50\nhither 0.1\nresolution 96 64\nb 0.2 0.3 0.5\n"
+            "l 3 -5 6\nl -4 -2 5 0.5 0.5 0.9\nf 0.8 0.7 0.6 %g %g 8 0 0\n" % (1.0 - ks, ks))
+    for k in range(5):
+        text += "s %g %g 0.5 0.5\n" % (-2.0 + k, 0.3 * (k % 2))
+    text += "p 4\n-5 -5 0\n5 -5 0\n5 5 0\n-5 5 0\n"
+    sc = rtamd.Scene.from_nff(gpu_ctx, text)
+    o = oracle.OracleScene(text)
+    of, ou, octr, _ = o.render(max_depth=6, min_contribution=cutoff, pow_mode=oracle.POW_PORTABLE, threads=4)
+    gf, gu, st = sc.render(rtamd.RenderOptions(max_depth=6, min_contribution=cutoff))
+    assert np.array_equal(bits(gf), bits(of)) and np.array_equal(gu, ou)
+    for k in RAY_KEYS:
+        assert st.as_dict()[k] == octr[k], k
+    assert st.levels == deepest + 1
+
+
 def test_ragged_resolutions(rtamd, oracle, gpu_ctx):
     text = read_nff("extra-onplane")
     for (w, h) in ((1, 1), (7, 5), (65, 33), (250, 9)):
