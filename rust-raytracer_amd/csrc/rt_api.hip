@@ -95,6 +95,11 @@ struct rt_context {
     DevBuf<float> out_f32;
     DevBuf<uint8_t> out_u8;
     bool kernels_ready = false;
+    // Sizes of the last finished frame's levels: how many blocks the next frame of the same scene and
+    // size launches per level.  Only a hint -- every kernel strides over its level whatever the grid.
+    const rt_scene* hint_scene = nullptr;
+    uint32_t hint_slots = 0, hint_depth = 0;
+    uint32_t hint_rays[RT_MAX_LEVELS] = {}, hint_lit[RT_MAX_LEVELS] = {};
 };
 
 struct rt_scene {
@@ -595,8 +600,20 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // largest plausible level and let blocks past the end exit (grid-stride inside).
     const uint32_t gridn = std::min<uint32_t>(grid0, 16384);
     const uint32_t grids = std::min<uint32_t>(grid0, 65535);  // per light: the launch is (grids, n_lights)
+    // With the sizes of the last frame of this scene at this size known, a level gets the blocks its
+    // rays need (a quarter more, at least one block per CU) instead of the most it could need:
+    // the blocks past a level's end only start, read the level's size and leave, but there are
+    // tens of thousands of them per launch and they hold wave slots while they do.
+    const bool hinted = ctx->hint_scene == scene && ctx->hint_slots == n_slots && ctx->hint_depth == opt->max_depth;
+    auto blocks_for = [&](uint64_t rays, uint32_t most) -> uint32_t {
+        if (!hinted) return most;
+        const uint64_t b = (rays + (rays >> 2) + RT_BLOCK - 1) / RT_BLOCK;
+        return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(b, 256));
+    };
     auto shadow_and_light = [&](uint32_t first, uint32_t last) -> int {
-        const uint32_t gs = first == 0 ? grids : gridn, gl = first == 0 ? grid0 : gridn;
+        uint64_t lit = 0, rays = 0;
+        for (uint32_t l = first; l <= last; ++l) { lit += ctx->hint_lit[l]; rays += ctx->hint_rays[l]; }
+        const uint32_t gs = first == 0 ? grids : blocks_for(lit, gridn), gl = first == 0 ? grid0 : blocks_for(rays, gridn);
         RT_HIP(ctx, hipStreamWaitEvent(st2, f.ev_level[last], 0));
         RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2)
                          : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
@@ -605,7 +622,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         return RT_OK;
     };
     for (uint32_t level = 0; level <= last_level; ++level) {
-        const uint32_t g = level == 0 ? grid0 : gridn;
+        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
         if (n_lights) {  // this level's shadow rays and lighting: beside the next levels, on the second stream
             RT_HIP(ctx, hipEventRecord(f.ev_level[level], st));
@@ -622,7 +639,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     }
     RT_HIP(ctx, hipEventRecord(f.ev[1], st));
     for (uint32_t level = last_level + 1; level-- > 0;) {
-        const uint32_t g = level == 0 ? grid0 : gridn;
+        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
         if (level == 0) RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_caller, 0));  // the caller's buffers are written from here on
         RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));
     }
@@ -670,6 +687,13 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
         for (int k = 0; k < 16; ++k) stats.work[k] = c[4 + k];
+        ctx->hint_scene = f.scene;
+        ctx->hint_slots = p.n_slots;
+        ctx->hint_depth = opt->max_depth;
+        for (uint32_t l = 0; l < RT_MAX_LEVELS; ++l) {
+            ctx->hint_rays[l] = l <= opt->max_depth ? lv[l] : 0u;
+            ctx->hint_lit[l] = l <= opt->max_depth ? lv[LV_SHADOW_COUNT + l] : 0u;
+        }
         stats.ray_nodes = p.n_slots;
         stats.levels = 1;
         for (uint32_t l = 1; l <= opt->max_depth; ++l) {
