@@ -613,7 +613,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     auto shadow_and_light = [&](uint32_t first, uint32_t last) -> int {
         uint64_t lit = 0, rays = 0;
         for (uint32_t l = first; l <= last; ++l) { lit += ctx->hint_lit[l]; rays += ctx->hint_rays[l]; }
-        const uint32_t gs = first == 0 ? grids : blocks_for(lit, gridn), gl = first == 0 ? grid0 : blocks_for(rays, gridn);
+        const uint32_t gs = blocks_for(lit, first == 0 ? grids : gridn), gl = first == 0 ? grid0 : blocks_for(rays, gridn);
         RT_HIP(ctx, hipStreamWaitEvent(st2, f.ev_level[last], 0));
         RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2)
                          : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
