@@ -610,15 +610,13 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         const uint64_t b = (rays + (rays >> 2) + RT_BLOCK - 1) / RT_BLOCK;
         return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(b, 256));
     };
-    auto shadow_and_light = [&](uint32_t first, uint32_t last) -> int {
-        uint64_t lit = 0, rays = 0;
-        for (uint32_t l = first; l <= last; ++l) { lit += ctx->hint_lit[l]; rays += ctx->hint_rays[l]; }
-        const uint32_t gs = blocks_for(lit, first == 0 ? grids : gridn), gl = first == 0 ? grid0 : blocks_for(rays, gridn);
+    auto shadow_rays = [&](uint32_t first, uint32_t last) -> int {
+        uint64_t lit = 0;
+        for (uint32_t l = first; l <= last; ++l) lit += ctx->hint_lit[l];
+        const uint32_t gs = blocks_for(lit, first == 0 ? grids : gridn);
         RT_HIP(ctx, hipStreamWaitEvent(st2, f.ev_level[last], 0));
         RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2)
                          : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
-        RT_HIP(ctx, fast ? rt_fast::launch_light(A, first, last, work, gl, st2)
-                         : rt_exact::launch_light(A, first, last, work, gl, st2));
         return RT_OK;
     };
     for (uint32_t level = 0; level <= last_level; ++level) {
@@ -628,12 +626,20 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
             RT_HIP(ctx, hipEventRecord(f.ev_level[level], st));
             if (level < SHADOW_GROUP_FROM || level == last_level) {
                 const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
-                rc = shadow_and_light(first, level);
+                rc = shadow_rays(first, level);
                 if (rc != RT_OK) return rc;
             }
         }
     }
     if (n_lights) {
+        {   // direct light of every node of the frame, once all shadow rays are traced: one launch, and
+            // no level's shadow rays wait behind an earlier level's lighting
+            uint64_t rays = n_slots;
+            for (uint32_t l = 1; l <= last_level; ++l) rays += ctx->hint_rays[l];
+            const uint32_t gl = hinted ? blocks_for(rays, 0x7fffffffu) : grid0 + gridn;
+            RT_HIP(ctx, fast ? rt_fast::launch_light(A, 0, last_level, work, gl, st2)
+                             : rt_exact::launch_light(A, 0, last_level, work, gl, st2));
+        }
         RT_HIP(ctx, hipEventRecord(f.ev_shadow, st2));
         RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_shadow, 0));
     }

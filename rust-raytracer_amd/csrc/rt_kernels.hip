@@ -14,8 +14,9 @@
 // small to fill the GPU, share one launch:
 //   k_shadow     closest hit of every shadow ray of a range of levels -> blocked flag
 //                (src/scene.rs:108-117);
-//   k_light      direct lighting of the nodes of those levels from their unblocked lights, in
-//                light order (src/scene.rs:119-124).
+//   k_light      direct lighting of the nodes of a range of levels from their unblocked lights,
+//                in light order (src/scene.rs:119-124): one launch over the whole frame's nodes
+//                once every shadow launch is done.
 // When both streams are done:
 //   k_resolve    from the deepest level up: total = direct + refl * reflectance + refr *
 //                transmittance in that order, clamped per node exactly as src/scene.rs:195 does
