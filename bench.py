@@ -103,6 +103,7 @@ def parse_args():
     ap.add_argument("--cpu-rows", type=int, default=32, help="rows of the frame the CPU baseline renders per leg")
     ap.add_argument("--lights", type=int, default=0, help="mount only: number of point lights")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--in-flight", default="auto", help="frames kept queued: a number, or auto = measured (2 or 4) before the warmup")
     return ap.parse_args()
 
 
@@ -147,9 +148,10 @@ def main():
     # launches that end a frame run beside the big ones that start the next.  Each frame's image
     # is complete, in HBM, before the next frame may write the buffer (stream order).
     pending, stats = [], []
+    in_flight = [2]
 
     def step():
-        if len(pending) == ctx.frames_in_flight:
+        if len(pending) >= in_flight[0]:
             stats.append(scene.render_device_end(pending.pop(0)))
         target = image if world == 1 else mine
         pending.append(scene.render_device_begin(opt, None, target.data_ptr(), stream))
@@ -168,6 +170,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # How many frames to keep queued: measured here, outside the timed region (long frames do best
+    # with two, frames of a few milliseconds with four); every rank takes the same decision.
+    if args.in_flight == "auto":
+        cand = [c for c in (2, 4) if c <= ctx.frames_in_flight]
+        took = []
+        for c in cand:
+            in_flight[0] = c
+            for _ in range(c):
+                step()
+            drain()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(max(8, 2 * c)):
+                step()
+            drain()
+            fence()
+            took.append(time.perf_counter() - t0)
+        t = torch.tensor(took, dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        in_flight[0] = cand[int(torch.argmin(t).item())]
+    else:
+        in_flight[0] = max(1, min(int(args.in_flight), ctx.frames_in_flight))
     for _ in range(args.warmup):
         step()
     drain()
@@ -251,7 +276,7 @@ def main():
         },
         "frame_ms": {"trace_kernels": round(float(mx[6]), 4), "resolve_kernels": round(float(mx[7]), 4),
                      "device_frame": round(float(mx[8]), 4), "step_wall": round(ms_per_step, 4),
-                     "frames_in_flight": ctx.frames_in_flight},
+                     "frames_in_flight": in_flight[0]},
         "roofline": {
             "bound": "valu",
             "kernel": "trace phase of one frame: k_intersect + k_shadow + k_light of every bounce level, two streams",

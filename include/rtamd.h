@@ -193,9 +193,12 @@ int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view
  * reference, which renders one image and exits).  rt_render_device_begin puts the frame on the
  * GPU and returns at once; rt_render_device_end waits for it, re-runs it with larger ray pools
  * if they overflowed, and fills the statistics.  At most rt_frames_in_flight(ctx) frames may
- * be in flight (2; 1 to 4 with the environment variable RTAMD_FRAMES_IN_FLIGHT read when the
+ * be in flight (4; fewer with the environment variable RTAMD_FRAMES_IN_FLIGHT read when the
  * context is created), begun and ended in the same order: the small launches that end one
- * frame then run beside the big launches that start the next.
+ * frame then run beside the big launches that start the next.  How many to keep queued is the
+ * caller's choice and worth measuring per scene: two suit long frames, four suit frames of a
+ * few milliseconds (a frame begun while two or more are in flight runs on one stream instead
+ * of two, so that four frames still fit the process's hardware queues).
  * Only the frame's last kernel touches the output buffers, and it is ordered after everything
  * `stream` held when begin was called; `stream` in turn waits for the frame, so work queued on
  * it afterwards (a copy, a gather) sees the finished image.  A ticket is free again once

@@ -423,7 +423,7 @@ class Scene:
         return st
 
     def render_device_begin(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0):
-        """Puts the frame on the GPU and returns a ticket at once (at most two in flight)."""
+        """Puts the frame on the GPU and returns a ticket at once (at most ctx.frames_in_flight queued)."""
         v = self.view(width, height)
         o = opt.c()
         ticket = C.c_uint32()
@@ -436,6 +436,42 @@ class Scene:
         st = rt_stats()
         self.ctx.check(lib().rt_render_device_end(self.ctx._h, ticket, C.byref(st)))
         return st
+
+    def render_frames(self, count, in_flight, opt, d_f32=None, d_u8=None, stream=None, width=0, height=0, sync=None,
+                      after_begin=None):
+        """Renders `count` frames of one view keeping `in_flight` queued; returns (seconds per frame,
+        list of rt_stats).  `after_begin()` runs after each frame is queued (a gather, a copy);
+        `sync()` waits for the device before the clock is read (e.g. torch.cuda.synchronize)."""
+        import time
+        pending, stats = [], []
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        for _ in range(count):
+            if len(pending) >= in_flight:
+                stats.append(self.render_device_end(pending.pop(0)))
+            pending.append(self.render_device_begin(opt, d_f32, d_u8, stream, width, height))
+            if after_begin:
+                after_begin()
+        while pending:
+            stats.append(self.render_device_end(pending.pop(0)))
+        if sync:
+            sync()
+        return (time.perf_counter() - t0) / max(1, count), stats
+
+    def tune_frames_in_flight(self, opt, d_f32=None, d_u8=None, stream=None, width=0, height=0, sync=None, after_begin=None,
+                              candidates=(2, 4), frames=8):
+        """How many frames to keep queued is worth measuring per scene (long frames: two; frames of a
+        few milliseconds: four): times `frames` frames for each candidate and returns
+        {candidate: seconds per frame}."""
+        times = {}
+        for c in candidates:
+            c = min(c, self.ctx.frames_in_flight)
+            if c in times:
+                continue
+            self.render_frames(c, c, opt, d_f32, d_u8, stream, width, height, sync, after_begin)  # (settle)
+            times[c] = self.render_frames(max(frames, 2 * c), c, opt, d_f32, d_u8, stream, width, height, sync, after_begin)[0]
+        return times
 
     def debug_intersect(self, src, ray, near, ignore, fp_mode=FP_EXACT):
         src = np.ascontiguousarray(src, dtype=np.float32)

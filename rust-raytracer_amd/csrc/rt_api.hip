@@ -76,6 +76,7 @@ struct FrameSlot {
     unsigned long long* h_counters = nullptr;        // itself (a blocking copy would wait for the other frame too)
     // the frame in flight
     bool busy = false;
+    bool one_stream = false;  // this frame's shadow launches go to the main stream too
     const rt_scene* scene = nullptr;
     rt_view view{};
     rt_options opt{};
@@ -90,7 +91,7 @@ struct rt_context {
     int device = 0;
     std::string err;
     FrameSlot slot[RT_MAX_FRAME_SLOTS];  // all set up, the first n_slots in use
-    uint32_t n_slots = 2;
+    uint32_t n_slots = RT_MAX_FRAME_SLOTS;
     uint32_t next_slot = 0;
     DevBuf<float> out_f32;
     DevBuf<uint8_t> out_u8;
@@ -181,8 +182,8 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
     RT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, RT_ERR_UNSUPPORTED, std::string("librtamd is built for gfx950 only; device is ") + prop.gcnArchName);
-    // Frames in flight: two keep one GPU busy with whole frames; a rank that renders a small
-    // share of a frame (1/8 of the tiles) is bound by launch latency and gains from more.
+    // Frames in flight: up to four workspaces (the caller decides how many it keeps queued; which
+    // number is fastest depends on the scene, see enqueue_frame).
     if (const char* s = getenv("RTAMD_FRAMES_IN_FLIGHT"))
         ctx->n_slots = std::min<uint32_t>(RT_MAX_FRAME_SLOTS, std::max<uint32_t>(1, (uint32_t)strtoul(s, nullptr, 10)));
     for (FrameSlot& f : ctx->slot) {
@@ -589,7 +590,11 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     const bool fast = opt->fp_mode == RT_FP_FAST;
     const bool work = opt->collect_work != 0;
     const bool cull = opt->exhaustive_leaves == 0;
-    hipStream_t st = f.main_stream, st2 = f.shadow_stream;
+    // Two streams per frame let a level's shadow rays run beside the next levels' intersections; HIP
+    // gives a process four hardware queues, so that is the schedule for up to two frames in flight.
+    // A caller that keeps three or four queued gets one stream per frame instead: the frames fill
+    // each other's gaps, and more streams than queues would only take turns on them.
+    hipStream_t st = f.main_stream, st2 = f.one_stream ? f.main_stream : f.shadow_stream;
     if (first_attempt) RT_HIP(ctx, hipEventRecord(f.ev_caller, f.caller));
     RT_HIP(ctx, hipMemsetAsync(f.levels.p, 0, LV_WORDS * sizeof(uint32_t), st));
     RT_HIP(ctx, hipMemsetAsync(f.counters.p, 0, 20 * sizeof(unsigned long long), st));
@@ -738,6 +743,11 @@ extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, co
     const uint32_t id = ctx->next_slot;
     FrameSlot& f = ctx->slot[id];
     if (f.busy) return fail(ctx, RT_ERR_INVALID, "every frame slot is in flight already: call rt_render_device_end first");
+    {
+        uint32_t busy = 0;
+        for (uint32_t k = 0; k < ctx->n_slots; ++k) busy += ctx->slot[k].busy ? 1u : 0u;
+        f.one_stream = busy >= 2;
+    }
     f.scene = scene;
     f.view = *view;
     f.opt = *opt;

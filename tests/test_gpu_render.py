@@ -299,8 +299,8 @@ def test_errors_through_the_abi(rtamd, gpu_ctx):
 
 def test_two_frames_in_flight(rtamd, oracle, gpu_ctx):
     """rt_render_device_begin / _end: frames of different views queued back to back (two in flight,
-    on alternating workspaces) give the images of one-at-a-time renders; a third begin without an
-    end is refused; the caller's stream sees each finished image."""
+    then as many as there are workspaces) give the images of one-at-a-time renders; a begin with
+    every workspace in flight is refused; the caller's stream sees each finished image."""
     import torch
     text = read_nff("extra-glass")
     sc = rtamd.Scene.from_nff(gpu_ctx, text)
@@ -315,14 +315,34 @@ def test_two_frames_in_flight(rtamd, oracle, gpu_ctx):
             assert st.rays_primary == sizes[k - 2][0] * sizes[k - 2][1]
         tickets.append(sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, outs[k].data_ptr(), stream, w, h))
         copies.append(outs[k].clone())  # queued on the caller's stream right behind the frame
+    # fill every workspace (frames begun with two or more in flight take the one-stream schedule),
+    # then one more is refused
+    spare = [torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda") for _ in range(gpu_ctx.frames_in_flight)]
+    while len(tickets) < gpu_ctx.frames_in_flight:
+        tickets.append(sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, spare[len(tickets)].data_ptr(), stream, 96, 64))
     with pytest.raises(rtamd.RtError):
-        sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, outs[0].data_ptr(), stream, 96, 64)
+        sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, spare[0].data_ptr(), stream, 96, 64)
     for t in tickets:
         sc.render_device_end(t)
     torch.cuda.synchronize()
     for k in range(len(sizes)):
         assert np.array_equal(outs[k].cpu().numpy(), want[k]), k
         assert np.array_equal(copies[k].cpu().numpy(), want[k]), k
+    for k in range(2, gpu_ctx.frames_in_flight):
+        assert np.array_equal(spare[k].cpu().numpy(), want[0]), k
+    # as many frames queued as there are workspaces, each into its own image
+    n = gpu_ctx.frames_in_flight
+    imgs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for (w, h) in sizes]
+    tickets = []
+    for k, (w, h) in enumerate(sizes):
+        if len(tickets) == n:
+            sc.render_device_end(tickets.pop(0))
+        tickets.append(sc.render_device_begin(rtamd.RenderOptions(max_depth=6), None, imgs[k].data_ptr(), stream, w, h))
+    for t in tickets:
+        sc.render_device_end(t)
+    torch.cuda.synchronize()
+    for k in range(len(sizes)):
+        assert np.array_equal(imgs[k].cpu().numpy(), want[k]), k
     # the same output buffer for consecutive frames: each frame's last kernel waits for the copy
     # the caller queued after the previous frame
     buf = torch.zeros((64, 96, 3), dtype=torch.uint8, device="cuda")

@@ -27,18 +27,11 @@ for name, gen, W, H, ranks in CONFIGS:
         opt = rt.RenderOptions(max_depth=8, tile_rank=0, tile_count=n)
         for _ in range(2):
             st = sc.render_device(opt, None, out.data_ptr(), stream)
-        K, pending = 8, []
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            if len(pending) == ctx.frames_in_flight:
-                sc.render_device_end(pending.pop(0))
-            pending.append(sc.render_device_begin(opt, None, out.data_ptr(), stream))
-        while pending:
-            st = sc.render_device_end(pending.pop(0))
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / K * 1e3
-        print("%s, rank 0 of %d: %.2f ms/frame, %d rays, %.0f Mrays/s on this GPU" % (name, n, ms, st.rays_total, st.rays_total / ms / 1e3),
+        times = sc.tune_frames_in_flight(opt, None, out.data_ptr(), stream, sync=torch.cuda.synchronize)
+        best = min(times, key=times.get)
+        sec, stats = sc.render_frames(8, best, opt, None, out.data_ptr(), stream, sync=torch.cuda.synchronize)
+        ms, st = sec * 1e3, stats[-1]
+        print("%s, rank 0 of %d: %.2f ms/frame (%d in flight), %d rays, %.0f Mrays/s on this GPU" % (name, n, ms, best, st.rays_total, st.rays_total / ms / 1e3),
               flush=True)
         del out
     del sc

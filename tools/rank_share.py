@@ -28,14 +28,7 @@ for n in (1, 2, 4, 8):
         sc.render_device(opt, None, out.data_ptr(), stream)
     torch.cuda.synchronize()
     one = (time.perf_counter() - t0) / K * 1e3
-    pending = []
-    t0 = time.perf_counter()
-    for it in range(K):
-        if len(pending) == ctx.frames_in_flight:
-            sc.render_device_end(pending.pop(0))
-        pending.append(sc.render_device_begin(opt, None, out.data_ptr(), stream))
-    while pending:
-        sc.render_device_end(pending.pop(0))
-    torch.cuda.synchronize()
-    two = (time.perf_counter() - t0) / K * 1e3
-    print("N=%d rank 0: device frame %.3f ms; wall per frame %.3f ms one at a time, %.3f ms with %d in flight; %d rays" % (n, st.ms_frame, one, two, ctx.frames_in_flight, st.rays_total))
+    times = sc.tune_frames_in_flight(opt, None, out.data_ptr(), stream, sync=torch.cuda.synchronize, frames=K)
+    best = min(times, key=times.get)
+    two = times[best] * 1e3
+    print("N=%d rank 0: device frame %.3f ms; wall per frame %.3f ms one at a time, %.3f ms with %d in flight; %d rays" % (n, st.ms_frame, one, two, best, st.rays_total))
