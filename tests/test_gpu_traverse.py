@@ -2,12 +2,27 @@
 of SpacePartition::intersect (reference src/space_partition.rs:268-385), on trees with
 interior nodes, with and without an ignored primitive, including rays that start inside
 the scene (reflection/shadow-like) and axis-parallel rays."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import read_nff
 
+SEED_SHIFT = 1000 * int(os.environ.get("RTAMD_TEST_SEED", "0"))  # (other ray and scene samples for a longer soak)
 pytestmark = pytest.mark.gpu
+
+
+def scene_or_skip(rtamd, gpu_ctx, text):
+    """(A random cloud can be a scene on which the reference's builder does not terminate: the
+    library refuses it, and a soak run with other seeds skips it.)"""
+    try:
+        return rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    except rtamd.RtError as e:
+        if "does not terminate" in str(e):
+            pytest.skip(str(e))
+        raise
+
 
 
 def bits(a):
@@ -41,12 +56,12 @@ def cases(spd):
 @pytest.mark.parametrize("name", ["lathe", "tetra", "mount", "balls3", "rings2", "onplane"])
 def test_closest_hit_matches_oracle(rtamd, oracle, spd, gpu_ctx, name):
     text = cases(spd)[name]
-    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    sc = scene_or_skip(rtamd, gpu_ctx, text)
     o = oracle.OracleScene(text, build_threads=4)
     t = o.tree()
     lo = t["boxes"][0, :3]
     hi = lo + t["boxes"][0, 3:]
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + SEED_SHIFT)
     src, d, near, ignore = make_rays(rng, 30000, lo, hi, o.info.n_prims)
     wp, wd, wn = o.intersect_rays(src, d, near, ignore)
     for flags in (0, rtamd.DEBUG_EXHAUSTIVE):
@@ -86,12 +101,12 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
     bit for bit, also for grazing rays (aimed at sphere silhouettes to within a few ulps), rays
     from far away, rays that are not unit length, and coordinates far from the origin where the
     reference's f32 discriminant accepts rays that geometrically miss."""
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SEED_SHIFT)
     offset = np.array(offset, np.float64)
     text, c, r = sphere_cloud(rng, 6003, scale, offset)  # not a multiple of 8: the run gets padding copies
-    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    sc = scene_or_skip(rtamd, gpu_ctx, text)
     o = oracle.OracleScene(text, build_threads=4)
-    assert o.info.max_leaf > 1000  # the degenerate build this test is about
+    assert SEED_SHIFT or o.info.max_leaf > 1000  # the degenerate build this test is about
     n = 40000
     far = rng.choice([0.3, 1.5, 4.0, 60.0, 3000.0], n)[:, None]
     src = offset + rng.normal(size=(n, 3)) * scale * far
@@ -123,7 +138,7 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
     assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
     hit = wp != 0xFFFFFFFF
-    assert 0.2 < (hit & (wp != 0)).mean() < 0.98  # both sphere hits and misses are exercised
+    assert SEED_SHIFT or 0.2 < (hit & (wp != 0)).mean() < 0.98  # both sphere hits and misses are exercised
 
 
 def polygon_cloud(rng, n, scale, offset):
@@ -167,12 +182,12 @@ def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offs
     Same bar as for spheres: primitive, distance bits and normal bits of the culled walk equal the
     exhaustive walk and the oracle, for rays through vertices and along edges (to a few ulps),
     rays almost inside a polygon's plane, origins on polygons and far away, unnormalised rays."""
-    rng = np.random.default_rng(13)
+    rng = np.random.default_rng(13 + SEED_SHIFT)
     offset = np.array(offset, np.float64)
     text, polys = polygon_cloud(rng, 3001, scale, offset)
-    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    sc = scene_or_skip(rtamd, gpu_ctx, text)
     o = oracle.OracleScene(text, build_threads=4)
-    assert o.info.max_leaf > 1000
+    assert SEED_SHIFT or o.info.max_leaf > 1000
     n = 40000
     pick = rng.integers(0, len(polys), n)
     tgt = np.zeros((n, 3))
@@ -208,7 +223,7 @@ def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offs
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
     hit = wp != 0xFFFFFFFF
     # (at the 1e-3 scale most polygons fail the reference's |ray . normal| >= 1e-6 test: few hits)
-    assert 0.05 < (hit & (wp != 0)).mean() < 0.98
+    assert SEED_SHIFT or 0.05 < (hit & (wp != 0)).mean() < 0.98
     # the fast build's plane normals differ in the last bits; its culling must still agree with
     # its own exhaustive walk
     fp, fd, fn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST | rtamd.DEBUG_EXHAUSTIVE)
@@ -258,12 +273,12 @@ def test_cylinder_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, off
     the exhaustive walk and the oracle, for rays grazing a cylinder's surface, rays (almost)
     along its axis or along its surface, origins on the axis, on cylinders and far away,
     unnormalised rays, and near values below zero (which the culled walk must not take)."""
-    rng = np.random.default_rng(29)
+    rng = np.random.default_rng(29 + SEED_SHIFT)
     offset = np.array(offset, np.float64)
     text, cyl = cylinder_cloud(rng, 2001, scale, offset)
-    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    sc = scene_or_skip(rtamd, gpu_ctx, text)
     o = oracle.OracleScene(text, build_threads=4)
-    assert o.info.max_leaf > 1000
+    assert SEED_SHIFT or o.info.max_leaf > 1000
     n = 40000
     pick = rng.integers(0, len(cyl), n)
     tgt = np.zeros((n, 3))
@@ -305,7 +320,7 @@ def test_cylinder_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, off
     assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
     hit = wp != 0xFFFFFFFF
-    assert 0.05 < (hit & (wp != 0)).mean() < 0.98
+    assert SEED_SHIFT or 0.05 < (hit & (wp != 0)).mean() < 0.98
     fp, fd, fn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST | rtamd.DEBUG_EXHAUSTIVE)
     cp, cd, cn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST)
     assert np.array_equal(cp, fp) and np.array_equal(bits(cd), bits(fd)) and np.array_equal(bits(cn), bits(fn))
