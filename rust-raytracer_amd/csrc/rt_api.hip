@@ -629,7 +629,15 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
         if (n_lights) {  // this level's shadow rays and lighting: beside the next levels, on the second stream
             RT_HIP(ctx, hipEventRecord(f.ev_level[level], st));
-            if (level < SHADOW_GROUP_FROM || level == last_level) {
+            if (f.one_stream) {
+                // one stream: the chain of intersections first, without a shadow launch between two
+                // levels, then every level's shadow rays in one launch (the other frames in flight
+                // fill the GPU under the small launches of the deep levels)
+                if (level == last_level) {
+                    rc = shadow_rays(0, level);
+                    if (rc != RT_OK) return rc;
+                }
+            } else if (level < SHADOW_GROUP_FROM || level == last_level) {
                 const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
                 rc = shadow_rays(first, level);
                 if (rc != RT_OK) return rc;
