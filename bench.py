@@ -279,7 +279,7 @@ def main():
                      "frames_in_flight": in_flight[0]},
         "roofline": {
             "bound": "valu",
-            "kernel": "trace phase of one frame: k_intersect + k_shadow + k_light of every bounce level, two streams",
+            "kernel": "trace phase of one frame: k_intersect of every bounce level, k_shadow, k_light",
             "achieved": round(flops / trace_s / 1e12, 4),
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",
