@@ -144,7 +144,7 @@ def main():
         gathered = torch.zeros((world, stride, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
         parts = list(gathered.unbind(0)) if rank == 0 else None
 
-    # Frames are queued without waiting for the previous one (two in flight at most): the small
+    # Frames are queued without waiting for the previous one (two or four in flight, whichever measured faster): the small
     # launches that end a frame run beside the big ones that start the next.  Each frame's image
     # is complete, in HBM, before the next frame may write the buffer (stream order).
     pending, stats = [], []
@@ -246,7 +246,7 @@ def main():
     nodes_frame = work["rays_primary"] + work["rays_reflect"] + work["rays_refract"]
     abytes = sum(work[k] * c for k, c in BYTES.items()) + nodes_frame * RAY_STATE_BYTES + W * H * FRAMEBUFFER_BYTES
     ms_per_step = elapsed_max / args.steps * 1e3
-    # GPU time one frame takes up: with two frames in flight their launches overlap, so a frame's
+    # GPU time one frame takes up: with several frames in flight their launches overlap, so a frame's
     # own first-to-last span (frame_ms.device_frame, its latency) counts shared time twice
     trace_s = min(float(mx[6]), ms_per_step) * 1e-3
     value = rays_frame * args.steps / elapsed_max / 1e6

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs on the GPU box: time per frame of ONE rank's share of the headline frame for N = 1, 2,
-4, 8 (interleaved 8x8 tiles) on a single GPU, one frame at a time and with two frames in
+4, 8 (interleaved 8x8 tiles) on a single GPU, one frame at a time and with two or four frames in
 flight.  No gather; shows how the per-rank frame shrinks."""
 import importlib
 import sys
