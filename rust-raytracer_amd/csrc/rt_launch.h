@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define RT_BLOCK 256
+#ifndef RT_BLOCK
+#define RT_BLOCK 128  // threads per block of every kernel (a block keeps its LDS and wave slots until its slowest wave is done)
+#endif
 #define RT_MAX_LEVELS 64  // max_depth + 2 must fit
 #define RT_LANE_WORDS 16
 // Traversal stack of the general kernels: the newest RT_STACK_RING entries of a lane sit in LDS,
