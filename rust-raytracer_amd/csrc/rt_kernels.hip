@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
     Ctr ctr;
     uint32_t n_refl = 0, n_refr = 0;
 
-    for (uint32_t chunk = blockIdx.x * RT_BLOCK; chunk < count; chunk += gridDim.x * RT_BLOCK) {
+    // (blockDim.x, not RT_BLOCK: the trace kernels of scenes with small leaves run in smaller blocks)
+    for (uint32_t chunk = blockIdx.x * blockDim.x; chunk < count; chunk += gridDim.x * blockDim.x) {
         const uint32_t i = chunk + threadIdx.x;
         const uint32_t node = base + i;
         Ray ray;
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A
     end = end < A.shadow_cap ? end : A.shadow_cap;
     const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
     Ctr ctr;
-    for (uint32_t k = first + blockIdx.x * RT_BLOCK + threadIdx.x; k < end; k += gridDim.x * RT_BLOCK) {
+    for (uint32_t k = first + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {
         const uint64_t i = queue + k;
         const float4 so = A.sray_o[i];
         const float4 sd = A.sray_d[i];
@@ -589,10 +590,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
 // ---------------------------------------------------------------------------------------
 // traversal stack + the per-lane words of the culled leaf walk
 // (the lean kernels keep the whole stack in LDS, the others its newest RT_STACK_RING entries)
-static size_t stack_bytes(const DevScene& S, bool lean_kernel) {
+static size_t stack_bytes(const DevScene& S, bool lean_kernel, uint32_t block = RT_BLOCK) {
     const size_t entries = lean_kernel ? S.stack_depth : RT_STACK_RING;
-    return entries * RT_BLOCK * sizeof(uint2) + (size_t)RT_LANE_WORDS * RT_BLOCK * sizeof(uint32_t);
+    return entries * block * sizeof(uint2) + (size_t)RT_LANE_WORDS * block * sizeof(uint32_t);
 }
+
+// Threads per block of the trace kernels.  A block keeps its LDS and wave slots until its slowest
+// wave is done, and waves of incoherent rays in trees of small leaves differ widely: those
+// scenes run one wave per block.  Lean scenes (a few huge sphere leaves) do best with two.
+// `grid` counts blocks of RT_BLOCK threads; the launch covers the same number of threads.
+static uint32_t trace_block(const DevScene& S) { return S.lean != 0 ? RT_BLOCK : RT_TRACE_BLOCK_GENERAL; }
 
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
 hipError_t init_kernels() {
@@ -615,9 +622,10 @@ hipError_t init_kernels() {
 
 // `work` selects the instrumented kernels, `cull` the culled walk of big leaves.
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
-    const dim3 g(grid), b(RT_BLOCK);
+    const uint32_t tb = trace_block(A.scene);
+    const dim3 g(grid * (RT_BLOCK / tb)), b(tb);
     const bool lean = A.scene.lean != 0;
-    const size_t lds = stack_bytes(A.scene, !work && cull && lean);
+    const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb);
     if (level == 0) {  // camera rays start outside the scene: the line test alone
         if (work && cull) hipLaunchKernelGGL((k_intersect<true, 1, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<true, 0, WorkCounters>), g, b, lds, st, A, level);
@@ -636,8 +644,9 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 
 hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, uint32_t grid,
                          hipStream_t st) {
-    const size_t lds = stack_bytes(A.scene, !work && cull && A.scene.lean != 0);
-    const dim3 g(grid, A.scene.n_lights), b(RT_BLOCK);
+    const uint32_t tb = trace_block(A.scene);
+    const size_t lds = stack_bytes(A.scene, !work && cull && A.scene.lean != 0, tb);
+    const dim3 g(grid * (RT_BLOCK / tb), A.scene.n_lights), b(tb);
     // shadow rays start on a surface, among the primitives, at every level: the behind-origin test pays
     const int mode = cull ? 2 : 0;
     const bool lean = A.scene.lean != 0;

@@ -7,6 +7,9 @@
 #ifndef RT_BLOCK
 #define RT_BLOCK 128  // threads per block of every kernel (a block keeps its LDS and wave slots until its slowest wave is done)
 #endif
+#ifndef RT_TRACE_BLOCK_GENERAL
+#define RT_TRACE_BLOCK_GENERAL 64  // threads per block of the trace kernels of scenes that are not lean (divides RT_BLOCK)
+#endif
 #define RT_MAX_LEVELS 64  // max_depth + 2 must fit
 #define RT_LANE_WORDS 16
 // Traversal stack of the general kernels: the newest RT_STACK_RING entries of a lane sit in LDS,
