@@ -202,11 +202,28 @@ int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view
  * Only the frame's last kernel touches the output buffers, and it is ordered after everything
  * `stream` held when begin was called; `stream` in turn waits for the frame, so work queued on
  * it afterwards (a copy, a gather) sees the finished image.  A ticket is free again once
- * rt_render_device_end has returned. */
+ * rt_render_device_end has returned.
+ * Ray pools.  A frame's rays live in pools whose needed size is only known once it has been
+ * traced; a frame that overflows them writes NOTHING to the output buffers and is run again
+ * with larger pools.  rt_render_device_begin itself waits for, and re-runs, any frame that is
+ * not like the last finished one (another scene, image share or depth, or the context's first),
+ * so the promise above holds for it; every slot's pools are then kept at the largest size any
+ * finished frame needed plus a quarter.  A later frame of the same kind whose rays outgrow even
+ * that (a camera move that brings a quarter more rays than any frame before) is only re-run by
+ * rt_render_device_end: rt_stats.retries > 0 then says that work queued on `stream` between
+ * begin and end found the buffers as they were before this frame, that they hold the frame
+ * only from end's return on, and that the re-run wrote them after whatever `stream` held by
+ * then (frames begun into the same buffers in the meantime included). */
 int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                            void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out);
 int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out);
 uint32_t rt_frames_in_flight(const rt_context* ctx);
+/* Upper bound, in bytes, on the ray pools ONE frame slot may hold (92 bytes per ray-tree node, 36
+ * per shadow ray; a context has rt_frames_in_flight slots, each used slot holds its own pools);
+ * 0 = no bound (default; the environment variable RTAMD_WORKSPACE_MAX_MB sets it at creation).
+ * A frame that needs more fails with RT_ERR_CAPACITY instead of allocating.  No counterpart in
+ * the reference, whose recursion keeps one ray at a time on the stack. */
+int rt_context_set_workspace_limit(rt_context* ctx, uint64_t bytes_per_frame_slot);
 
 /* ---- interleaved 8x8 tiles over ranks (pure index math + one device kernel) ---- */
 

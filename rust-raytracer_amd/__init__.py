@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
-    "rt_debug_bound", "rt_frames_in_flight",
+    "rt_debug_bound", "rt_frames_in_flight", "rt_context_set_workspace_limit",
 )
 
 
@@ -202,6 +202,7 @@ def lib():
     L.rt_debug_bound.restype = C.c_int
     L.rt_frames_in_flight.argtypes = [vp]
     L.rt_frames_in_flight.restype = C.c_uint32
+    L.rt_context_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.rt_debug_intersect.argtypes = [vp, vp, C.c_uint32, C.c_uint64] + [vp] * 7
     L.rt_debug_eval.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
     _lib = L
@@ -315,6 +316,10 @@ class Context:
         """How many frames render_device_begin may have queued at once."""
         return int(lib().rt_frames_in_flight(self._h))
 
+    def set_workspace_limit(self, bytes_per_frame_slot: int):
+        """Bound on the ray pools one frame slot may hold (0 = none); frames needing more raise RT_ERR_CAPACITY."""
+        self.check(lib().rt_context_set_workspace_limit(self._h, bytes_per_frame_slot))
+
     def check(self, rc):
         if rc != RT_OK:
             raise RtError(rc, lib().rt_last_error(self._h).decode())
@@ -380,12 +385,17 @@ class Scene:
             lib().rt_scene_destroy(h)
             self._h = None
 
-    def view(self, width=0, height=0):
+    def view(self, width=0, height=0, from_=None, at=None):
+        """The scene file's view, optionally at another size or from another camera position."""
         v = rt_view.from_buffer_copy(self.parsed.view)
         if width:
             v.width = width
         if height:
             v.height = height
+        if from_ is not None:
+            v.from_[:] = [float(x) for x in from_]
+        if at is not None:
+            v.at[:] = [float(x) for x in at]
         return v
 
     def tree(self):
@@ -413,18 +423,18 @@ class Scene:
         self.ctx.check(lib().rt_render(self.ctx._h, self._h, C.byref(v), C.byref(o), _ptr(f32), _ptr(u8), C.byref(st)))
         return f32, u8, st
 
-    def render_device(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0):
+    def render_device(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0, view=None):
         """Device-pointer form (ints or None); returns rt_stats after the frame completed."""
-        v = self.view(width, height)
+        v = view if view is not None else self.view(width, height)
         st = rt_stats()
         o = opt.c()
         self.ctx.check(lib().rt_render_device(self.ctx._h, self._h, C.byref(v), C.byref(o), d_f32, d_u8, stream,
                                               C.byref(st)))
         return st
 
-    def render_device_begin(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0):
+    def render_device_begin(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0, view=None):
         """Puts the frame on the GPU and returns a ticket at once (at most ctx.frames_in_flight queued)."""
-        v = self.view(width, height)
+        v = view if view is not None else self.view(width, height)
         o = opt.c()
         ticket = C.c_uint32()
         self.ctx.check(lib().rt_render_device_begin(self.ctx._h, self._h, C.byref(v), C.byref(o), d_f32, d_u8, stream,

@@ -52,19 +52,33 @@ struct DevBuf {
 
 }  // namespace
 
-// Everything one frame in flight owns.  A context has two, so that the small, latency-bound
+// The device memory a frame works in: where its kernels find it.  A frame slot's pools own theirs
+// (hipMalloc, grown on demand); the slot of the entry point that allocates nothing points into
+// the library's static device array instead.
+struct Workspace {
+    float4 *ray_o = nullptr, *ray_d = nullptr, *node_col = nullptr, *hit_a = nullptr, *sray_o = nullptr, *sray_d = nullptr;
+    uint32_t *hit_p = nullptr, *sray_blocked = nullptr;
+    uint2* node_sh = nullptr;
+    uint4* node_kid = nullptr;
+    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_count[RT_MAX_LEVELS] | overflow
+    uint32_t* levels = nullptr;
+    unsigned long long* counters = nullptr;
+    size_t pool_cap = 0;    // ray-tree nodes
+    size_t shadow_cap = 0;  // shadow-ray slots, all lights' queues together
+};
+
+// Everything one frame in flight owns.  A context has four, so that the small, latency-bound
 // launches at the end of one frame can run beside the big first launches of the next.
 struct FrameSlot {
     // workspace, kept across frames and grown on demand
     DevBuf<float4> ray_o, ray_d, node_col, hit_a, sray_o, sray_d;
     DevBuf<uint32_t> hit_p, sray_blocked;
     DevBuf<uint2> node_sh;
-    size_t shadow_cap = 0;
     DevBuf<uint4> node_kid;
-    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_count[RT_MAX_LEVELS] | overflow
     DevBuf<uint32_t> levels;
     DevBuf<unsigned long long> counters;
-    size_t pool_cap = 0;
+    Workspace ws;           // what the kernels are given: the buffers above, or a share of the static array
+    bool fixed = false;     // ws is a share of the static array: never grown, never re-run
     hipStream_t main_stream = nullptr;    // the frame's kernels
     hipStream_t shadow_stream = nullptr;  // shadow rays of a level run here, beside the next levels
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // timing: start, traced, resolved
@@ -76,6 +90,9 @@ struct FrameSlot {
     unsigned long long* h_counters = nullptr;        // itself (a blocking copy would wait for the other frame too)
     // the frame in flight
     bool busy = false;
+    bool finished = false;    // waited for and its statistics kept in `stats` already (rt_render_device_begin did)
+    int finish_rc = 0;
+    rt_stats stats{};
     bool one_stream = false;  // this frame's shadow launches go to the main stream too
     const rt_scene* scene = nullptr;
     rt_view view{};
@@ -93,6 +110,10 @@ struct rt_context {
     FrameSlot slot[RT_MAX_FRAME_SLOTS];  // all set up, the first n_slots in use
     uint32_t n_slots = RT_MAX_FRAME_SLOTS;
     uint32_t next_slot = 0;
+    // Pool sizes every slot is brought to before a frame: the largest any finished frame needed,
+    // with headroom, so that a slot's first frame does not overflow where another's already has.
+    size_t want_pool = 0, want_shadow1 = 0;
+    uint64_t workspace_limit = 0;        // bytes of pools per frame slot the caller allows; 0 = no limit
     DevBuf<float> out_f32;
     DevBuf<uint8_t> out_u8;
     bool kernels_ready = false;
@@ -140,26 +161,85 @@ float bits_to_float(uint32_t u) {
     return f;
 }
 
+constexpr size_t NODE_BYTES = 4 * sizeof(float4) + sizeof(uint4) + sizeof(uint32_t) + sizeof(uint2);  // per ray-tree node
+constexpr size_t SHADOW_BYTES = 2 * sizeof(float4) + sizeof(uint32_t);                                 // per shadow-ray slot
+
+// Both leave the slot consistent when an allocation fails: the whole set released, capacity 0.
 int ensure_pool(rt_context* ctx, FrameSlot& f, size_t cap) {
-    if (f.pool_cap >= cap) return RT_OK;
-    RT_HIP(ctx, f.ray_o.alloc(cap));
-    RT_HIP(ctx, f.ray_d.alloc(cap));
-    RT_HIP(ctx, f.node_col.alloc(cap));
-    RT_HIP(ctx, f.node_kid.alloc(cap));
-    RT_HIP(ctx, f.hit_a.alloc(cap));
-    RT_HIP(ctx, f.hit_p.alloc(cap));
-    RT_HIP(ctx, f.node_sh.alloc(cap));
-    f.pool_cap = cap;
+    if (f.ws.pool_cap >= cap) return RT_OK;
+    if (f.fixed) return fail(ctx, RT_ERR_CAPACITY, "the static workspace holds fewer ray-tree nodes than this frame needs");
+    f.ws.pool_cap = 0;
+    hipError_t e = f.ray_o.alloc(cap);
+    if (e == hipSuccess) e = f.ray_d.alloc(cap);
+    if (e == hipSuccess) e = f.node_col.alloc(cap);
+    if (e == hipSuccess) e = f.node_kid.alloc(cap);
+    if (e == hipSuccess) e = f.hit_a.alloc(cap);
+    if (e == hipSuccess) e = f.hit_p.alloc(cap);
+    if (e == hipSuccess) e = f.node_sh.alloc(cap);
+    if (e != hipSuccess) {
+        f.ray_o.release(); f.ray_d.release(); f.node_col.release(); f.node_kid.release();
+        f.hit_a.release(); f.hit_p.release(); f.node_sh.release();
+        (void)hipGetLastError();
+        return fail(ctx, RT_ERR_DEVICE, std::string("ray pool of ") + std::to_string(cap) + " nodes: " + hipGetErrorString(e));
+    }
+    f.ws.ray_o = f.ray_o.p; f.ws.ray_d = f.ray_d.p; f.ws.node_col = f.node_col.p; f.ws.node_kid = f.node_kid.p;
+    f.ws.hit_a = f.hit_a.p; f.ws.hit_p = f.hit_p.p; f.ws.node_sh = f.node_sh.p;
+    f.ws.pool_cap = cap;
     return RT_OK;
 }
 
 int ensure_shadow(rt_context* ctx, FrameSlot& f, size_t cap) {
-    if (f.shadow_cap >= cap) return RT_OK;
-    RT_HIP(ctx, f.sray_o.alloc(cap));
-    RT_HIP(ctx, f.sray_d.alloc(cap));
-    RT_HIP(ctx, f.sray_blocked.alloc(cap));
-    f.shadow_cap = cap;
+    if (f.ws.shadow_cap >= cap) return RT_OK;
+    if (f.fixed) return fail(ctx, RT_ERR_CAPACITY, "the static workspace holds fewer shadow rays than this frame needs");
+    f.ws.shadow_cap = 0;
+    hipError_t e = f.sray_o.alloc(cap);
+    if (e == hipSuccess) e = f.sray_d.alloc(cap);
+    if (e == hipSuccess) e = f.sray_blocked.alloc(cap);
+    if (e != hipSuccess) {
+        f.sray_o.release(); f.sray_d.release(); f.sray_blocked.release();
+        (void)hipGetLastError();
+        return fail(ctx, RT_ERR_DEVICE, std::string("shadow queues of ") + std::to_string(cap) + " rays: " + hipGetErrorString(e));
+    }
+    f.ws.sray_o = f.sray_o.p; f.ws.sray_d = f.sray_d.p; f.ws.sray_blocked = f.sray_blocked.p;
+    f.ws.shadow_cap = cap;
     return RT_OK;
+}
+
+int prepare_kernels(rt_context* ctx) {
+    if (ctx->kernels_ready) return RT_OK;
+    RT_HIP(ctx, rt_exact::init_kernels());
+    RT_HIP(ctx, rt_fast::init_kernels());
+    ctx->kernels_ready = true;
+    return RT_OK;
+}
+
+// Streams, events and the pinned copies of a slot's counters.
+int setup_slot(rt_context* ctx, FrameSlot& f) {
+    for (auto& e : f.ev) RT_HIP(ctx, hipEventCreate(&e));
+    RT_HIP(ctx, hipStreamCreateWithFlags(&f.main_stream, hipStreamNonBlocking));
+    RT_HIP(ctx, hipStreamCreateWithFlags(&f.shadow_stream, hipStreamNonBlocking));
+    for (auto& e : f.ev_level) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_shadow, hipEventDisableTiming));
+    RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_caller, hipEventDisableTiming));
+    RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
+    RT_HIP(ctx, hipHostMalloc((void**)&f.h_levels, LV_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    RT_HIP(ctx, hipHostMalloc((void**)&f.h_counters, 20 * sizeof(unsigned long long), hipHostMallocDefault));
+    return RT_OK;
+}
+
+void teardown_slot(FrameSlot& f) {
+    if (f.busy && f.main_stream) (void)hipStreamSynchronize(f.main_stream);
+    for (auto& e : f.ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : f.ev_level)
+        if (e) (void)hipEventDestroy(e);
+    if (f.ev_shadow) (void)hipEventDestroy(f.ev_shadow);
+    if (f.ev_caller) (void)hipEventDestroy(f.ev_caller);
+    if (f.ev_done) (void)hipEventDestroy(f.ev_done);
+    if (f.h_levels) (void)hipHostFree(f.h_levels);
+    if (f.h_counters) (void)hipHostFree(f.h_counters);
+    if (f.shadow_stream) (void)hipStreamDestroy(f.shadow_stream);
+    if (f.main_stream) (void)hipStreamDestroy(f.main_stream);
 }
 
 }  // namespace
@@ -187,37 +267,24 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
     if (const char* s = getenv("RTAMD_FRAMES_IN_FLIGHT"))
         ctx->n_slots = std::min<uint32_t>(RT_MAX_FRAME_SLOTS, std::max<uint32_t>(1, (uint32_t)strtoul(s, nullptr, 10)));
     for (FrameSlot& f : ctx->slot) {
-        for (auto& e : f.ev) RT_HIP(ctx, hipEventCreate(&e));
-        RT_HIP(ctx, hipStreamCreateWithFlags(&f.main_stream, hipStreamNonBlocking));
-        RT_HIP(ctx, hipStreamCreateWithFlags(&f.shadow_stream, hipStreamNonBlocking));
-        for (auto& e : f.ev_level) RT_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_shadow, hipEventDisableTiming));
-        RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_caller, hipEventDisableTiming));
-        RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
-        RT_HIP(ctx, hipHostMalloc((void**)&f.h_levels, LV_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-        RT_HIP(ctx, hipHostMalloc((void**)&f.h_counters, 20 * sizeof(unsigned long long), hipHostMallocDefault));
+        int rc = setup_slot(ctx, f);
+        if (rc != RT_OK) return rc;
         RT_HIP(ctx, f.levels.alloc(LV_WORDS));
         RT_HIP(ctx, f.counters.alloc(20));
+        f.ws.levels = f.levels.p;
+        f.ws.counters = f.counters.p;
+    }
+    if (const char* s = getenv("RTAMD_WORKSPACE_MAX_MB")) ctx->workspace_limit = (uint64_t)strtoull(s, nullptr, 10) << 20;
+    {
+        int rc = prepare_kernels(ctx);
+        if (rc != RT_OK) return rc;
     }
     return RT_OK;
 }
 
 extern "C" void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
-    for (FrameSlot& f : ctx->slot) {
-        if (f.busy && f.main_stream) (void)hipStreamSynchronize(f.main_stream);
-        for (auto& e : f.ev)
-            if (e) (void)hipEventDestroy(e);
-        for (auto& e : f.ev_level)
-            if (e) (void)hipEventDestroy(e);
-        if (f.ev_shadow) (void)hipEventDestroy(f.ev_shadow);
-        if (f.ev_caller) (void)hipEventDestroy(f.ev_caller);
-        if (f.ev_done) (void)hipEventDestroy(f.ev_done);
-        if (f.h_levels) (void)hipHostFree(f.h_levels);
-        if (f.h_counters) (void)hipHostFree(f.h_counters);
-        if (f.shadow_stream) (void)hipStreamDestroy(f.shadow_stream);
-        if (f.main_stream) (void)hipStreamDestroy(f.main_stream);
-    }
+    for (FrameSlot& f : ctx->slot) teardown_slot(f);
     delete ctx;
 }
 
@@ -248,7 +315,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
                 ti.n_leaves++;
                 ti.max_leaf = std::max(ti.max_leaf, n.over);
             } else {
-                depth[n.under] = depth[n.over] = depth[i] + 1;
+                depth[n.under] = std::max(depth[n.under], depth[i] + 1);
+                depth[n.over] = std::max(depth[n.over], depth[i] + 1);
             }
             ti.max_depth = std::max(ti.max_depth, depth[i]);
         }
@@ -466,18 +534,6 @@ extern "C" int rt_scene_tree_copy(const rt_scene* scene, rt_kd_node* nodes, uint
 
 namespace {
 
-int prepare_kernels(rt_context* ctx) {
-    if (ctx->kernels_ready) return RT_OK;
-    RT_HIP(ctx, rt_exact::init_kernels());
-    RT_HIP(ctx, rt_fast::init_kernels());
-    ctx->kernels_ready = true;
-    return RT_OK;
-}
-
-}  // namespace
-
-namespace {
-
 struct FramePlan {  // what enqueue and finish both need about a frame
     uint32_t n_slots = 0, n_lights = 0;
     uint64_t n_primary = 0;
@@ -513,7 +569,7 @@ int plan_frame(rt_context* ctx, const FrameSlot& f, FramePlan& p) {
 // Nothing here waits for the GPU.  The kernels run on the slot's own stream; only the last one
 // (resolve of level 0, the one that writes the caller's buffers) is ordered after what the
 // caller's stream held when the frame began, and the caller's stream then waits for the frame.
-int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap, size_t scap, bool first_attempt) {
+int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap, size_t scap) {
     const rt_scene* scene = f.scene;
     const rt_view* view = &f.view;
     const rt_options* opt = &f.opt;
@@ -522,6 +578,13 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     const uint32_t n_slots = p.n_slots, n_lights = p.n_lights;
     if (cap > 0xfffffff0ull || scap * p.lights1 > 0xfffffff0ull)
         return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
+    if (!f.fixed && ctx->workspace_limit != 0 &&
+        (uint64_t)std::max(cap, f.ws.pool_cap) * NODE_BYTES + (uint64_t)std::max(scap * p.lights1, f.ws.shadow_cap) * SHADOW_BYTES >
+            ctx->workspace_limit)
+        return fail(ctx, RT_ERR_CAPACITY,
+                    "this frame needs " + std::to_string((cap * NODE_BYTES + scap * p.lights1 * SHADOW_BYTES) >> 20) +
+                        " MiB of ray pools, more than the workspace limit of " + std::to_string(ctx->workspace_limit >> 20) +
+                        " MiB per frame slot (rt_context_set_workspace_limit, RTAMD_WORKSPACE_MAX_MB)");
     int rc = ensure_pool(ctx, f, cap);
     if (rc != RT_OK) return rc;
     rc = ensure_shadow(ctx, f, scap * p.lights1);
@@ -546,23 +609,24 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.min_contribution = opt->min_contribution;
     A.out_f32 = (float*)f.out_f32;
     A.out_u8 = (uint8_t*)f.out_u8;
-    A.ray_o = f.ray_o.p;
-    A.ray_d = f.ray_d.p;
-    A.hit_a = f.hit_a.p;
-    A.hit_p = f.hit_p.p;
-    A.node_sh = f.node_sh.p;
-    A.node_col = f.node_col.p;
-    A.node_kid = f.node_kid.p;
-    A.pool_cap = (uint32_t)f.pool_cap;
-    A.sray_o = f.sray_o.p;
-    A.sray_d = f.sray_d.p;
-    A.sray_blocked = f.sray_blocked.p;
-    A.shadow_cap = (uint32_t)(f.shadow_cap / p.lights1);
-    A.level_count = f.levels.p;
-    A.level_base = f.levels.p + RT_MAX_LEVELS;
-    A.shadow_count = f.levels.p + LV_SHADOW_COUNT;
-    A.overflow = f.levels.p + LV_OVERFLOW;
-    A.counters = f.counters.p;
+    const Workspace& ws = f.ws;
+    A.ray_o = ws.ray_o;
+    A.ray_d = ws.ray_d;
+    A.hit_a = ws.hit_a;
+    A.hit_p = ws.hit_p;
+    A.node_sh = ws.node_sh;
+    A.node_col = ws.node_col;
+    A.node_kid = ws.node_kid;
+    A.pool_cap = (uint32_t)ws.pool_cap;
+    A.sray_o = ws.sray_o;
+    A.sray_d = ws.sray_d;
+    A.sray_blocked = ws.sray_blocked;
+    A.shadow_cap = (uint32_t)(ws.shadow_cap / p.lights1);
+    A.level_count = ws.levels;
+    A.level_base = ws.levels + RT_MAX_LEVELS;
+    A.shadow_count = ws.levels + LV_SHADOW_COUNT;
+    A.overflow = ws.levels + LV_OVERFLOW;
+    A.counters = ws.counters;
 
     // Levels that cannot hold a ray are not launched.  A ray of level k carries a contribution of
     // at most w^k, w the largest reflectance in the scene, when nothing transmits (a surface with
@@ -595,9 +659,12 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // A caller that keeps three or four queued gets one stream per frame instead: the frames fill
     // each other's gaps, and more streams than queues would only take turns on them.
     hipStream_t st = f.main_stream, st2 = f.one_stream ? f.main_stream : f.shadow_stream;
-    if (first_attempt) RT_HIP(ctx, hipEventRecord(f.ev_caller, f.caller));
-    RT_HIP(ctx, hipMemsetAsync(f.levels.p, 0, LV_WORDS * sizeof(uint32_t), st));
-    RT_HIP(ctx, hipMemsetAsync(f.counters.p, 0, 20 * sizeof(unsigned long long), st));
+    // What the caller's stream holds now comes before this attempt's writes to the caller's buffers.
+    // (A re-run from rt_render_device_end records it afresh: frames begun in the meantime into the
+    // same buffers, and whatever consumes them, are on that stream by then.)
+    RT_HIP(ctx, hipEventRecord(f.ev_caller, f.caller));
+    RT_HIP(ctx, hipMemsetAsync(ws.levels, 0, LV_WORDS * sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(ws.counters, 0, 20 * sizeof(unsigned long long), st));
     RT_HIP(ctx, hipEventRecord(f.ev[0], st));
 
     const uint32_t grid0 = std::max<uint32_t>(1, (n_slots + RT_BLOCK - 1) / RT_BLOCK);
@@ -664,14 +731,15 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     }
     RT_HIP(ctx, hipEventRecord(f.ev[2], st));
     RT_HIP(ctx, hipStreamWaitEvent(f.caller, f.ev[2], 0));
-    RT_HIP(ctx, hipMemcpyAsync(f.h_levels, f.levels.p, LV_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipMemcpyAsync(f.h_counters, f.counters.p, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(f.h_levels, ws.levels, LV_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(f.h_counters, ws.counters, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipEventRecord(f.ev_done, st));
     return RT_OK;
 }
 
 // Waits for the frame of slot `f`, grows the pools and runs it again if they overflowed, and
-// fills the statistics.
+// fills the statistics.  An attempt that overflowed has written nothing to the caller's buffers
+// (the last kernel checks the flag).
 int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
     FramePlan p;
     int rc = plan_frame(ctx, f, p);
@@ -683,21 +751,29 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
     for (uint32_t attempt = 0;; ++attempt) {
         RT_HIP(ctx, hipEventSynchronize(f.ev_done));
         memcpy(lv, f.h_levels, sizeof(lv));
+        const size_t shadow_cap1 = f.ws.shadow_cap / p.lights1;
+        uint64_t need = p.n_slots, sneed = 0;
+        for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed += lv[LV_SHADOW_COUNT + l];
+        for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
         if (lv[LV_OVERFLOW] != 0) {  // a pool overflowed: grow and run the frame again
-            const size_t shadow_cap1 = f.shadow_cap / p.lights1;
-            uint64_t need = p.n_slots, sneed = 0;
-            for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed += lv[LV_SHADOW_COUNT + l];
-            for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
-            size_t cap = f.pool_cap, scap = shadow_cap1;
-            if (need > f.pool_cap) cap = std::max<size_t>(f.pool_cap * 2, (size_t)need + (need >> 2));
+            if (f.fixed)
+                return fail(ctx, RT_ERR_CAPACITY,
+                            "the frame's rays do not fit the static workspace (" + std::to_string(need) + "+ ray-tree nodes of " +
+                                std::to_string(f.ws.pool_cap) + ", " + std::to_string(sneed) + "+ lit hits of " +
+                                std::to_string(shadow_cap1) + "); nothing was written to the outputs");
+            size_t cap = f.ws.pool_cap, scap = shadow_cap1;
+            if (need > f.ws.pool_cap) cap = std::max<size_t>(f.ws.pool_cap * 2, (size_t)need + (need >> 2));
             if (sneed > shadow_cap1) scap = std::max<size_t>(shadow_cap1 * 2, (size_t)sneed + (sneed >> 2));
-            if (need <= f.pool_cap && sneed <= shadow_cap1) { cap = f.pool_cap * 2; scap = shadow_cap1 * 2; }
+            if (need <= f.ws.pool_cap && sneed <= shadow_cap1) { cap = f.ws.pool_cap * 2; scap = shadow_cap1 * 2; }
             stats.retries = attempt + 1;
             if (attempt >= 8) return fail(ctx, RT_ERR_CAPACITY, "ray pool still too small after 8 growth steps");
-            rc = enqueue_frame(ctx, f, p, cap, scap, false);
+            rc = enqueue_frame(ctx, f, p, cap, scap);
             if (rc != RT_OK) return rc;
             continue;
         }
+        // what the next frames' pools should hold, on every slot: this frame's need and a quarter more
+        ctx->want_pool = std::max<size_t>(ctx->want_pool, (size_t)need + (need >> 2));
+        ctx->want_shadow1 = std::max<size_t>(ctx->want_shadow1, (size_t)sneed + (sneed >> 2));
         unsigned long long c[20];
         memcpy(c, f.h_counters, sizeof(c));
         stats.rays_primary = p.n_primary;
@@ -732,11 +808,9 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
     return RT_OK;
 }
 
-}  // namespace
-
-extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
-                                      void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out) {
-    if (!ctx || !scene || !view || !opt || !ticket_out) return fail(ctx, RT_ERR_INVALID, "null argument");
+// Argument checks shared by the entry points that start a frame.
+int check_frame_args(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt) {
+    if (!ctx || !scene || !view || !opt) return fail(ctx, RT_ERR_INVALID, "null argument");
     if (scene->ctx != ctx) return fail(ctx, RT_ERR_INVALID, "scene belongs to another context");
     if (view->width == 0 || view->height == 0) return fail(ctx, RT_ERR_INVALID, "empty view");
     if ((uint64_t)view->width * view->height > 0x7fffffffull / 3) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large");
@@ -745,8 +819,18 @@ extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, co
     const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
     if (opt->tile_rank >= tile_count) return fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_count");
     if (scene->dev.n_lights > 65535) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 65535 lights");
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                                      void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out) {
+    if (!ticket_out) return fail(ctx, RT_ERR_INVALID, "null argument");
+    int rc = check_frame_args(ctx, scene, view, opt);
+    if (rc != RT_OK) return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = prepare_kernels(ctx);
+    rc = prepare_kernels(ctx);
     if (rc != RT_OK) return rc;
     const uint32_t id = ctx->next_slot;
     FrameSlot& f = ctx->slot[id];
@@ -765,13 +849,29 @@ extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, co
     FramePlan p;
     rc = plan_frame(ctx, f, p);
     if (rc != RT_OK) return rc;
-    const size_t cap = std::max<size_t>(f.pool_cap, std::max<size_t>((size_t)p.n_slots * 2, 1u << 16));
-    // shadow queues hold the whole frame: room for the primary hits and about as many again,
-    // times the number of lights
-    const size_t scap = std::max<size_t>(f.shadow_cap / p.lights1, std::max<size_t>((size_t)p.n_slots * 2, 1u << 16));
-    rc = enqueue_frame(ctx, f, p, cap, scap, true);
+    // Pools: what this slot has, what finished frames on any slot needed (and a quarter more), and
+    // room for the camera rays and as many again.  Shadow queues hold the whole frame's lit hits,
+    // times the number of lights.
+    const size_t floor_cap = std::max<size_t>((size_t)p.n_slots * 2, 1u << 16);
+    const size_t cap = std::max(std::max(f.ws.pool_cap, ctx->want_pool), floor_cap);
+    const size_t scap = std::max(std::max(f.ws.shadow_cap / p.lights1, ctx->want_shadow1), floor_cap);
+    // A frame like the last finished one (same scene, image share and depth) is known to fit pools of
+    // that size, or to come close.  Any other frame is waited for here, pools grown and the frame
+    // re-run as often as it takes, so that what the caller queues on `stream` after this call finds
+    // the finished image.
+    const bool proven = ctx->hint_scene == scene && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth;
+    rc = enqueue_frame(ctx, f, p, cap, scap);
     if (rc != RT_OK) return rc;
     f.busy = true;
+    f.finished = false;
+    if (!proven) {
+        f.finish_rc = finish_frame(ctx, f, &f.stats);
+        f.finished = true;
+        if (f.finish_rc != RT_OK) {
+            f.busy = false;
+            return f.finish_rc;
+        }
+    }
     ctx->next_slot = (id + 1u) % ctx->n_slots;
     *ticket_out = id;
     return RT_OK;
@@ -782,9 +882,20 @@ extern "C" int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* 
     FrameSlot& f = ctx->slot[ticket];
     if (!f.busy) return fail(ctx, RT_ERR_INVALID, "no frame in flight under this ticket");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    const int rc = finish_frame(ctx, f, stats_out);
+    int rc = RT_OK;
+    if (f.finished) {
+        if (stats_out) *stats_out = f.stats;
+    } else {
+        rc = finish_frame(ctx, f, stats_out);
+    }
     f.busy = false;
     return rc;
+}
+
+extern "C" int rt_context_set_workspace_limit(rt_context* ctx, uint64_t bytes_per_frame_slot) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->workspace_limit = bytes_per_frame_slot;
+    return RT_OK;
 }
 
 extern "C" uint32_t rt_frames_in_flight(const rt_context* ctx) { return ctx ? ctx->n_slots : 0; }

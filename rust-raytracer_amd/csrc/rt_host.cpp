@@ -69,6 +69,7 @@ int validate_desc(const rt_scene_desc& d, std::string& err) {
     if (d.nodes) {
         if (d.n_nodes == 0) { err = "prebuilt partition with zero nodes"; return RT_ERR_INVALID; }
         if (d.n_leaf_refs && !d.leaf_refs) { err = "null leaf_refs"; return RT_ERR_INVALID; }
+        std::vector<uint8_t> has_parent(d.n_nodes, 0);
         for (uint32_t i = 0; i < d.n_nodes; ++i) {
             const rt_kd_node& n = d.nodes[i];
             if (n.axis > 3) { err = "node axis out of range"; return RT_ERR_INVALID; }
@@ -78,6 +79,14 @@ int validate_desc(const rt_scene_desc& d, std::string& err) {
                 // children must come after their parent: this also rules out cycles
                 err = "interior node child index out of range";
                 return RT_ERR_INVALID;
+            } else {
+                // a tree: the device's traversal stack is sized by the depth, which is only well
+                // defined when every node has one parent
+                if (n.under == n.over || has_parent[n.under] || has_parent[n.over]) {
+                    err = "node with more than one parent";
+                    return RT_ERR_INVALID;
+                }
+                has_parent[n.under] = has_parent[n.over] = 1;
             }
         }
         for (uint32_t i = 0; i < d.n_leaf_refs; ++i)

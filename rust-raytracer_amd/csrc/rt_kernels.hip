@@ -275,6 +275,9 @@ template <int CULL, class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A, uint32_t first_level, uint32_t last_level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
+    // A frame whose pools overflowed is run again with larger ones: its shadow rays are wasted
+    // work, and queue slots the overflowing wave never wrote hold no rays at all.
+    if (*A.overflow != 0u) return;
     const uint32_t first = shadow_first(A, first_level);
     uint32_t end = shadow_first(A, last_level + 1);
     end = end < A.shadow_cap ? end : A.shadow_cap;
@@ -301,6 +304,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A
 template <class Ctr>
 __global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t first_level, uint32_t last_level) {
     const DevScene& S = A.scene;
+    if (*A.overflow != 0u) return;  // (the frame will be run again)
     const uint32_t first = first_level == 0 ? 0u : A.level_base[first_level];
     const uint32_t end = A.level_base[last_level + 1];  // both already clamped to the pool
     Ctr ctr;
@@ -346,6 +350,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t first_
 // ---------------------------------------------------------------------------------------
 template <bool LEVEL0>
 __global__ void __launch_bounds__(RT_BLOCK) k_resolve(FrameArgs A, uint32_t level) {
+    // An attempt whose pools overflowed dropped rays: its image would be wrong, so it writes none
+    // (the caller's buffers keep what they held until the re-run with larger pools).
+    if (*A.overflow != 0u) return;
     const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
     const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {

@@ -654,9 +654,13 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
             if constexpr (LEAN) q2.w = 0u;  // (there are no cones)
             const uint32_t together = MODE != 0 ? q2.w : q2.y + q2.w + q3.y;
             if (together >= BIG_LEAF) {
+                // Lanes walk together only when they stand on the same leaf with the same entries left:
+                // a lane that walked the leaf's cylinder records above has fewer cone items left than
+                // one that could not (near < 0, or a ray the bounding tests cannot take).
+                const uint32_t key = cur * 2u + (cyl_n != 0u ? 1u : 0u);
                 bool mine_done = false;
                 while (!mine_done) {
-                    if (cur == (uint32_t)__builtin_amdgcn_readfirstlane(cur)) {
+                    if (key == (uint32_t)__builtin_amdgcn_readfirstlane(key)) {
                         // (read again inside the branch: these copies stay in scalar registers)
                         const uint4 u2 = make_uint4(__builtin_amdgcn_readfirstlane(q2.x), __builtin_amdgcn_readfirstlane(q2.y),
                                                     __builtin_amdgcn_readfirstlane(q2.z), __builtin_amdgcn_readfirstlane(q2.w));

@@ -281,7 +281,134 @@ def test_pool_growth_retry(rtamd, oracle, gpu_ctx):
     sc = rtamd.Scene.from_nff(ctx, text)
     gf, _, st = sc.render(rtamd.RenderOptions(max_depth=10), 256, 256)
     of, _, _, _ = oracle.OracleScene(text).render(256, 256, max_depth=10, pow_mode=oracle.POW_PORTABLE, threads=8)
+    assert st.retries >= 1  # (or this test no longer exercises the growth path)
     assert np.array_equal(bits(gf), bits(of))
+
+
+MIRROR_HALL = ("v\nfrom 0 -3.5 1\nat 0 0 1\nup 0 0 1\nangle 60\nhither 0.1\nresolution 128 96\nb 0.1 0.1 0.2\n"
+               "l 0 0 1.9\nl 1 -1 1.5 1 0.8 0.6\nl -1 1 0.4 0.5 0.7 1\nl 0.5 0.5 1\nl -0.5 -2 1.7\n"
+               "f 0.9 0.9 0.9 0.2 0.8 20 0 0\n"
+               "p 4\n-2 -4 0\n2 -4 0\n2 4 0\n-2 4 0\n" "p 4\n-2 -4 2\n-2 4 2\n2 4 2\n2 -4 2\n"
+               "p 4\n-2 -4 0\n-2 4 0\n-2 4 2\n-2 -4 2\n" "p 4\n2 -4 0\n2 -4 2\n2 4 2\n2 4 0\n"
+               "p 4\n-2 4 0\n2 4 0\n2 4 2\n-2 4 2\n" "p 4\n-2 -4 0\n-2 -4 2\n2 -4 2\n2 -4 0\n"
+               "f 1 0.3 0.2 0.3 0.7 40 0 0\ns 0.6 0.5 0.6 0.5\ns -0.7 1.5 0.5 0.45\n")
+
+
+def test_shadow_queue_growth_retry(rtamd, oracle):
+    """A closed hall of mirrors with five lights: every ray hits a lit surface at every level,
+    so the shadow queues (one slot per lit hit and light) overflow together with the ray pool on
+    a fresh context; the re-run frame must be the oracle's, to the bit and to the ray."""
+    ctx = rtamd.Context(0)
+    sc = rtamd.Scene.from_nff(ctx, MIRROR_HALL)
+    gf, gu, st = sc.render(rtamd.RenderOptions(max_depth=9), 256, 256)
+    of, ou, octr, _ = oracle.OracleScene(MIRROR_HALL).render(256, 256, max_depth=9, pow_mode=oracle.POW_PORTABLE, threads=8)
+    assert st.retries >= 1
+    assert octr["rays_shadow"] // 5 > 2 * 256 * 256  # more lit hits than a fresh queue holds
+    assert np.array_equal(bits(gf), bits(of)) and np.array_equal(gu, ou)
+    for k in RAY_KEYS:
+        assert st.as_dict()[k] == octr[k], k
+
+
+def test_first_frame_overflow_is_settled_before_begin_returns(rtamd, oracle):
+    """The first frame of a scene on a fresh context overflows its pools.  rt_render_device_begin
+    re-runs it itself, so a copy queued on the caller's stream right after begin is the finished
+    image, and the attempt that overflowed has written nothing."""
+    import torch
+    ctx = rtamd.Context(0)
+    text = read_nff("extra-glass")
+    sc = rtamd.Scene.from_nff(ctx, text)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = torch.full((256, 256, 3), 7, dtype=torch.uint8, device="cuda")
+    ticket = sc.render_device_begin(rtamd.RenderOptions(max_depth=10), None, out.data_ptr(), stream, 256, 256)
+    copy = out.clone()
+    st = sc.render_device_end(ticket)
+    torch.cuda.synchronize()
+    _, ou, octr, _ = oracle.OracleScene(text).render(256, 256, max_depth=10, pow_mode=oracle.POW_PORTABLE, threads=8)
+    assert st.retries >= 1
+    assert np.array_equal(copy.cpu().numpy(), ou) and np.array_equal(out.cpu().numpy(), ou)
+    for k in RAY_KEYS:
+        assert st.as_dict()[k] == octr[k], k
+    # every slot starts at the size that frame needed: four more in flight, none re-run
+    outs = [torch.zeros((256, 256, 3), dtype=torch.uint8, device="cuda") for _ in range(ctx.frames_in_flight)]
+    tickets = [sc.render_device_begin(rtamd.RenderOptions(max_depth=10), None, o.data_ptr(), stream, 256, 256) for o in outs]
+    copies = [o.clone() for o in outs]
+    for t in tickets:
+        assert sc.render_device_end(t).retries == 0
+    torch.cuda.synchronize()
+    for c in copies:
+        assert np.array_equal(c.cpu().numpy(), ou)
+
+
+def test_overflow_of_a_later_frame_is_reported_and_writes_nothing_early(rtamd, oracle):
+    """A frame of a known kind (same scene, size and depth as the last one) is queued without
+    waiting.  When a camera move makes it outgrow the pools all the same, the attempt that
+    overflowed leaves the output buffer as it was, rt_render_device_end re-runs it and says so
+    in rt_stats.retries, and the buffer holds the exact image once end has returned."""
+    import torch
+    ctx = rtamd.Context(0)
+    text = read_nff("extra-glass")
+    sc = rtamd.Scene.from_nff(ctx, text)
+    stream = torch.cuda.current_stream().cuda_stream
+    opt = rtamd.RenderOptions(max_depth=10)
+    away = sc.view(256, 256)
+    away.at[:] = [2.0 * away.from_[k] - away.at[k] for k in range(3)]  # looking the other way: background only
+    out = torch.full((256, 256, 3), 7, dtype=torch.uint8, device="cuda")
+    st0 = sc.render_device(opt, None, out.data_ptr(), stream, view=away)
+    assert st0.retries == 0 and st0.rays_total == 256 * 256
+    before = out.clone()
+    ticket = sc.render_device_begin(opt, None, out.data_ptr(), stream, 256, 256)
+    early = out.clone()  # queued between begin and end
+    st = sc.render_device_end(ticket)
+    torch.cuda.synchronize()
+    _, ou, octr, _ = oracle.OracleScene(text).render(256, 256, max_depth=10, pow_mode=oracle.POW_PORTABLE, threads=8)
+    assert st.retries >= 1
+    assert torch.equal(early, before)  # untouched, not a picture with rays missing
+    assert np.array_equal(out.cpu().numpy(), ou)
+    for k in RAY_KEYS:
+        assert st.as_dict()[k] == octr[k], k
+
+
+def test_workspace_limit(rtamd):
+    ctx = rtamd.Context(0)
+    sc = rtamd.Scene.from_nff(ctx, read_nff("extra-glass"))
+    ctx.set_workspace_limit(1 << 20)
+    with pytest.raises(rtamd.RtError) as e:
+        sc.render(rtamd.RenderOptions(max_depth=5), 256, 256)
+    assert e.value.code == rtamd.RT_ERR_CAPACITY and "workspace limit" in str(e.value)
+    ctx.set_workspace_limit(0)
+    sc.render(rtamd.RenderOptions(max_depth=5), 256, 256)
+
+
+def test_prebuilt_partition_must_be_a_tree(rtamd, gpu_ctx):
+    """A caller's own partition is adopted only if every node has one parent (the traversal
+    stack is sized by the tree's depth)."""
+    import ctypes as C
+    parsed = rtamd.ParsedScene(read_nff("extra-onplane"))
+    info, nodes, refs = parsed.build_tree()
+    assert info.n_nodes >= 5
+    def create(nodes_arr):
+        desc = rtamd.rt_scene_desc.from_buffer_copy(parsed.desc)
+        desc.n_nodes, desc.n_leaf_refs = len(nodes_arr), len(refs)
+        desc.nodes = nodes_arr.ctypes.data_as(C.POINTER(rtamd.rt_kd_node))
+        desc.leaf_refs = refs.ctypes.data_as(C.POINTER(C.c_uint32))
+        h = C.c_void_p()
+        rc = rtamd.lib().rt_scene_create(gpu_ctx._h, C.byref(desc), C.byref(h))
+        if rc == rtamd.RT_OK:
+            rtamd.lib().rt_scene_destroy(h)
+        return rc
+    assert create(nodes.copy()) == rtamd.RT_OK
+    bad = nodes.copy()
+    interior = [i for i in range(len(bad)) if bad[i]["axis"] != 3]
+    i = interior[0]
+    bad[i]["over"] = bad[i]["under"]  # both links to one child
+    assert create(bad) == rtamd.RT_ERR_INVALID
+    if len(interior) >= 2:
+        bad = nodes.copy()
+        a, b = interior[0], interior[-1]
+        last_leaf = max(j for j in range(len(bad)) if bad[j]["axis"] == 3)
+        if last_leaf > b and bad[b]["under"] != last_leaf and bad[b]["over"] != last_leaf:
+            bad[b]["under"] = last_leaf  # a second parent for a node that has one
+            assert create(bad) == rtamd.RT_ERR_INVALID
 
 
 def test_errors_through_the_abi(rtamd, gpu_ctx):

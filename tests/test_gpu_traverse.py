@@ -231,7 +231,7 @@ def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offs
     assert np.array_equal(cp, fp) and np.array_equal(bits(cd), bits(fd)) and np.array_equal(bits(cn), bits(fn))
 
 
-def cylinder_cloud(rng, n, scale, offset):
+def cylinder_cloud(rng, n, scale, offset, cone_every=97):
     """A floor over a cloud of cylinders (``c`` with equal radii): oblique, axis-aligned, needles,
     discs, plus a few cones proper, which stay outside the bounding records."""
     lines = ["v", "from %g %g %g" % tuple(offset + scale * np.array([3.0, 3.0, 2.0])), "at %g %g %g" % tuple(offset),
@@ -258,7 +258,7 @@ def cylinder_cloud(rng, n, scale, offset):
         base = (c - axis * length / 2).astype(np.float32)
         apex = (c + axis * length / 2).astype(np.float32)
         r = np.float32(radius)
-        ra = r if k % 97 else np.float32(radius * 0.5)  # (a cone proper now and then)
+        ra = r if k % cone_every else np.float32(radius * 0.5)  # (a cone proper now and then)
         cyl.append((base, apex, r, ra))
         lines.append("c")
         lines.append("%.9g %.9g %.9g %.9g" % (base[0], base[1], base[2], r))
@@ -324,3 +324,31 @@ def test_cylinder_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, off
     fp, fd, fn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST | rtamd.DEBUG_EXHAUSTIVE)
     cp, cd, cn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST)
     assert np.array_equal(cp, fp) and np.array_equal(bits(cd), bits(fd)) and np.array_equal(bits(cn), bits(fn))
+
+
+def test_lanes_with_and_without_the_cylinder_walk_share_a_leaf(rtamd, oracle, gpu_ctx):
+    """Neighbouring lanes alternate between near = 0 (cylinders walked through their bounding
+    records, only the cones proper left for the walk all lanes of a leaf do together) and
+    near < 0 (cylinders and cones proper all left for it) on one leaf with enough cones proper
+    for that shared walk: every lane must still test its own set of entries."""
+    rng = np.random.default_rng(61 + SEED_SHIFT)
+    text, cyl = cylinder_cloud(rng, 420, 1.0, np.zeros(3), cone_every=7)  # 60 cones proper, 360 cylinders
+    sc = scene_or_skip(rtamd, gpu_ctx, text)
+    o = oracle.OracleScene(text, build_threads=4)
+    assert SEED_SHIFT or o.info.max_leaf > 400
+    n = 16384
+    pick = rng.integers(0, len(cyl), n)
+    tgt = np.stack([(cyl[k][0].astype(np.float64) + cyl[k][1]) / 2 + rng.normal(size=3) * float(cyl[k][2]) * 0.5 for k in pick])
+    src = rng.normal(size=(n, 3)) * 2.5
+    d = tgt - src
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    src, d = src.astype(np.float32), d.astype(np.float32)
+    near = np.where(np.arange(n) % 2 == 0, np.float32(0.0), np.float32(-1.0)).astype(np.float32)
+    near[n // 2:] = np.where(rng.random(n - n // 2) < 0.5, np.float32(0.0), np.float32(-1.0))
+    ignore = np.full(n, 0xFFFFFFFF, np.uint32)
+    wp, wd, wn = o.intersect_rays(src, d, near, ignore)
+    ep, ed, en = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_EXHAUSTIVE)
+    gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
+    assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
+    assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    assert SEED_SHIFT or (wp != 0xFFFFFFFF).mean() > 0.5
