@@ -225,6 +225,21 @@ uint32_t rt_frames_in_flight(const rt_context* ctx);
  * the reference, whose recursion keeps one ray at a time on the stack. */
 int rt_context_set_workspace_limit(rt_context* ctx, uint64_t bytes_per_frame_slot);
 
+/* rt_render_device for callers that cannot allocate device memory at the time of the call: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments, same image, same statistics; but the frame's
+ * ray pools, shadow queues and counters live in a static device array of
+ * RT_STATIC_WORKSPACE_BYTES that each GPU the library runs on holds from load to exit, and the
+ * call allocates and frees nothing (streams, events and pinned counters were made by
+ * rt_context_create).  A frame whose rays do not fit -- about RT_STATIC_WORKSPACE_BYTES /
+ * (92 + 36 * lights) ray-tree nodes, camera rays included -- fails with RT_ERR_CAPACITY and
+ * writes nothing to the outputs; it is never re-run with more room.  Every call on one GPU, from
+ * any context, works in the same array: calls that overlap on one GPU race.  Returns after the
+ * frame has completed. */
+#define RT_STATIC_WORKSPACE_BYTES (64u << 20)
+int rt_render_device_static(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                            void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out);
+
 /* ---- interleaved 8x8 tiles over ranks (pure index math + one device kernel) ---- */
 
 /* Number of pixel slots in the compact tile buffer of `rank` (64 per tile, edge tiles padded). */

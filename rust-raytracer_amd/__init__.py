@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
-    "rt_debug_bound", "rt_frames_in_flight", "rt_context_set_workspace_limit",
+    "rt_debug_bound", "rt_frames_in_flight", "rt_context_set_workspace_limit", "rt_render_device_static",
 )
 
 
@@ -171,6 +171,7 @@ def lib():
     L.rt_scene_tree_copy.argtypes = [vp, vp, vp]
     L.rt_render.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, C.POINTER(rt_stats)]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, vp, C.POINTER(rt_stats)]
+    L.rt_render_device_static.argtypes = L.rt_render_device.argtypes
     L.rt_render_device_begin.argtypes = [vp, vp, C.POINTER(rt_view), C.POINTER(rt_options), vp, vp, vp,
                                          C.POINTER(C.c_uint32)]
     L.rt_render_device_end.argtypes = [vp, C.c_uint32, C.POINTER(rt_stats)]
@@ -430,6 +431,16 @@ class Scene:
         o = opt.c()
         self.ctx.check(lib().rt_render_device(self.ctx._h, self._h, C.byref(v), C.byref(o), d_f32, d_u8, stream,
                                               C.byref(st)))
+        return st
+
+    def render_device_static(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0, view=None):
+        """render_device in the library's static device workspace: allocates nothing; frames whose
+        rays do not fit it raise RT_ERR_CAPACITY."""
+        v = view if view is not None else self.view(width, height)
+        st = rt_stats()
+        o = opt.c()
+        self.ctx.check(lib().rt_render_device_static(self.ctx._h, self._h, C.byref(v), C.byref(o), d_f32, d_u8, stream,
+                                                     C.byref(st)))
         return st
 
     def render_device_begin(self, opt: RenderOptions, d_f32=None, d_u8=None, stream=None, width=0, height=0, view=None):

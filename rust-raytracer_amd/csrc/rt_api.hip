@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,13 @@
 #endif
 
 using namespace rtamd;
+
+// Workspace of rt_render_device_static, the entry point that allocates nothing: ray pools, shadow
+// queues and counters of one frame live in this array instead of hipMalloc'd buffers.  Every GPU
+// the library runs on holds its own copy, at its own address, until the process ends.  In host
+// code the name is only a handle for hipGetSymbolAddress: what kernels, memsets and copies are
+// given is the address looked up per device in scratch_address().
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_WORKSPACE_BYTES];
 
 namespace {
 
@@ -110,6 +118,8 @@ struct rt_context {
     FrameSlot slot[RT_MAX_FRAME_SLOTS];  // all set up, the first n_slots in use
     uint32_t n_slots = RT_MAX_FRAME_SLOTS;
     uint32_t next_slot = 0;
+    FrameSlot fixed_slot;                // rt_render_device_static: its workspace is a share of `scratch`
+    unsigned char* scratch_ptr = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress)
     // Pool sizes every slot is brought to before a frame: the largest any finished frame needed,
     // with headroom, so that a slot's first frame does not overflow where another's already has.
     size_t want_pool = 0, want_shadow1 = 0;
@@ -213,6 +223,25 @@ int prepare_kernels(rt_context* ctx) {
     return RT_OK;
 }
 
+// Device address of `scratch` on `device`, which must be the current device: looked up once per
+// device and kept (each GPU has its own copy of the array at its own address).
+constexpr int MAX_DEVICES = 64;
+unsigned char* g_scratch_ptr[MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+int scratch_address(rt_context* ctx, int device, unsigned char** out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(ctx, RT_ERR_INVALID, "device id out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        RT_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(ctx, RT_ERR_DEVICE, "no device address for the static workspace");
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 // Streams, events and the pinned copies of a slot's counters.
 int setup_slot(rt_context* ctx, FrameSlot& f) {
     for (auto& e : f.ev) RT_HIP(ctx, hipEventCreate(&e));
@@ -275,6 +304,16 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         f.ws.counters = f.counters.p;
     }
     if (const char* s = getenv("RTAMD_WORKSPACE_MAX_MB")) ctx->workspace_limit = (uint64_t)strtoull(s, nullptr, 10) << 20;
+    // The entry point that allocates nothing works in the static array: this device's copy of it
+    // is looked up here, with the device current, and its slot's streams, events and pinned
+    // counters are made now, so that the entry point itself has nothing left to set up.
+    {
+        int rc = scratch_address(ctx, ctx->device, &ctx->scratch_ptr);
+        if (rc != RT_OK) return rc;
+        ctx->fixed_slot.fixed = true;
+        rc = setup_slot(ctx, ctx->fixed_slot);
+        if (rc != RT_OK) return rc;
+    }
     {
         int rc = prepare_kernels(ctx);
         if (rc != RT_OK) return rc;
@@ -285,6 +324,7 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
 extern "C" void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
     for (FrameSlot& f : ctx->slot) teardown_slot(f);
+    teardown_slot(ctx->fixed_slot);
     delete ctx;
 }
 
@@ -896,6 +936,66 @@ extern "C" int rt_context_set_workspace_limit(rt_context* ctx, uint64_t bytes_pe
     if (!ctx) return RT_ERR_INVALID;
     ctx->workspace_limit = bytes_per_frame_slot;
     return RT_OK;
+}
+
+// The same frame as rt_render_device with every byte of device workspace taken from `scratch`:
+// no hipMalloc, hipFree or other allocating call, here or below.  The array is shared by every
+// call on this GPU and keeps the last call's contents; the frame clears the counters it needs at
+// zero itself (enqueue_frame), everything else is written before it is read.
+extern "C" int rt_render_device_static(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                                       void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {
+    int rc = check_frame_args(ctx, scene, view, opt);
+    if (rc != RT_OK) return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    FrameSlot& f = ctx->fixed_slot;
+    if (f.busy || !ctx->scratch_ptr || !ctx->kernels_ready) return fail(ctx, RT_ERR_INVALID, "context not ready");
+    f.scene = scene;
+    f.view = *view;
+    f.opt = *opt;
+    f.out_f32 = d_rgb_f32_out;
+    f.out_u8 = d_rgb_u8_out;
+    f.caller = (hipStream_t)stream;
+    f.one_stream = false;
+    FramePlan p;
+    rc = plan_frame(ctx, f, p);
+    if (rc != RT_OK) return rc;
+    // Shares of the array: counters first, then the node arrays and the shadow queues, all for the
+    // same number of entries (a frame has at most one lit hit per ray-tree node).  That number is a
+    // multiple of 64, which keeps every array on a 256-byte boundary.
+    constexpr size_t HEAD = 4096;
+    static_assert(LV_WORDS * sizeof(uint32_t) <= 2048 && 20 * sizeof(unsigned long long) <= 2048, "counters fit the head");
+    const size_t per_entry = NODE_BYTES + SHADOW_BYTES * p.lights1;
+    const size_t cap = ((RT_STATIC_WORKSPACE_BYTES - HEAD) / per_entry) & ~(size_t)63;
+    if (cap < p.n_slots || cap < 64)
+        return fail(ctx, RT_ERR_CAPACITY,
+                    "frame too large for the static workspace: " + std::to_string(p.n_slots) + " camera rays, room for " +
+                        std::to_string(cap) + " ray-tree nodes with " + std::to_string(p.n_lights) + " lights in " +
+                        std::to_string(RT_STATIC_WORKSPACE_BYTES >> 20) + " MiB");
+    unsigned char* at = ctx->scratch_ptr;
+    Workspace& ws = f.ws;
+    ws.levels = (uint32_t*)at;
+    ws.counters = (unsigned long long*)(at + 2048);
+    at += HEAD;
+    auto take = [&](size_t bytes) { unsigned char* q = at; at += bytes; return q; };
+    ws.ray_o = (float4*)take(cap * sizeof(float4));
+    ws.ray_d = (float4*)take(cap * sizeof(float4));
+    ws.node_col = (float4*)take(cap * sizeof(float4));
+    ws.hit_a = (float4*)take(cap * sizeof(float4));
+    ws.node_kid = (uint4*)take(cap * sizeof(uint4));
+    ws.node_sh = (uint2*)take(cap * sizeof(uint2));
+    ws.hit_p = (uint32_t*)take(cap * sizeof(uint32_t));
+    ws.sray_o = (float4*)take(cap * p.lights1 * sizeof(float4));
+    ws.sray_d = (float4*)take(cap * p.lights1 * sizeof(float4));
+    ws.sray_blocked = (uint32_t*)take(cap * p.lights1 * sizeof(uint32_t));
+    ws.pool_cap = cap;
+    ws.shadow_cap = cap * p.lights1;
+    if ((size_t)(at - ctx->scratch_ptr) > RT_STATIC_WORKSPACE_BYTES) return fail(ctx, RT_ERR_CAPACITY, "static workspace layout");
+    rc = enqueue_frame(ctx, f, p, cap, cap);
+    if (rc != RT_OK) return rc;
+    f.busy = true;
+    rc = finish_frame(ctx, f, stats_out);
+    f.busy = false;
+    return rc;
 }
 
 extern "C" uint32_t rt_frames_in_flight(const rt_context* ctx) { return ctx ? ctx->n_slots : 0; }
