@@ -63,6 +63,9 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.oracle_scene_from_nff.restype = C.c_void_p
         L.oracle_scene_from_nff.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        L.oracle_scene_from_nff_with_tree.restype = C.c_void_p
+        L.oracle_scene_from_nff_with_tree.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                      C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
         L.oracle_scene_free.argtypes = [C.c_void_p]
         L.oracle_scene_info.argtypes = [C.c_void_p, C.POINTER(OracleInfo)]
         L.oracle_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_uint32,
@@ -97,11 +100,24 @@ class OracleScene:
     """A parsed NFF scene with its space partition built (reference nff::read +
     Scene::build_space_partition)."""
 
-    def __init__(self, nff_text, use_phong: bool = True, build_threads: int = 1):
+    def __init__(self, nff_text, use_phong: bool = True, build_threads: int = 1, tree=None, verify_max: int = 2048):
+        """tree = (nodes, leaf_refs): a flat partition (64-byte node records, numpy) to adopt instead
+        of building one -- for scenes whose O(n^2) construction is out of reach of the CPU.  The oracle
+        re-derives every list and box itself and recomputes the decision of every node of at most
+        `verify_max` primitives; self.tree_checked = (nodes recomputed, nodes adopted)."""
         if isinstance(nff_text, str):
             nff_text = nff_text.encode()
         err = C.create_string_buffer(512)
-        self._h = lib().oracle_scene_from_nff(nff_text, len(nff_text), int(use_phong), build_threads, err, 512)
+        self.tree_checked = None
+        if tree is None:
+            self._h = lib().oracle_scene_from_nff(nff_text, len(nff_text), int(use_phong), build_threads, err, 512)
+        else:
+            nodes, refs = np.ascontiguousarray(tree[0]), np.ascontiguousarray(tree[1], dtype=np.uint32)
+            assert nodes.dtype.itemsize == 64
+            counts = np.zeros(2, dtype=np.uint64)
+            self._h = lib().oracle_scene_from_nff_with_tree(nff_text, len(nff_text), int(use_phong), _p(nodes), len(nodes),
+                                                            _p(refs), len(refs), verify_max, build_threads, _p(counts), err, 512)
+            self.tree_checked = (int(counts[0]), int(counts[1]))
         if not self._h:
             raise ValueError(err.value.decode())
         self.info = OracleInfo()

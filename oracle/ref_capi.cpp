@@ -67,6 +67,134 @@ void* oracle_scene_from_nff(const char* text, size_t len, int use_phong, int bui
     return h;
 }
 
+// A partition handed in as the flat 64-byte node records of include/rtamd.h (the layout is
+// restated here so that the oracle includes nothing of the product) instead of built: for scenes
+// whose O(n^2) construction takes the CPU hours (10^5 polygons).  Nothing of it is taken on
+// trust that the oracle can check in reasonable time: every node's primitive list is re-derived
+// with the oracle's own split() from the root down, every leaf's list and every node's box must
+// equal the records, and every node of at most `verify_max` primitives has its decision -- leaf,
+// or plane and child boxes -- recomputed by the oracle's find_splitting_plane.  Larger nodes'
+// decisions are adopted (the product's builder is held to the oracle's, byte for byte, on whole
+// smaller scenes elsewhere).
+struct FlatNode {
+    float bmin[3], plane, bmax[3];
+    uint32_t axis, under, over, parent, depth;
+    float extent[3];
+    uint32_t pad;
+};
+static_assert(sizeof(FlatNode) == 64, "flat node layout");
+
+struct AdoptCtx {
+    const FlatNode* nodes;
+    uint64_t n_nodes;
+    const uint32_t* refs;
+    uint64_t n_refs;
+    uint64_t verify_max;
+    int threads;
+    uint64_t verified = 0, adopted = 0;
+    BuildStats st;
+    std::string err;
+};
+
+static bool same_box(const BBox& b, const FlatNode& f) {
+    const float c[3] = {b.corner.x, b.corner.y, b.corner.z}, e[3] = {b.extent.x, b.extent.y, b.extent.z};
+    return memcmp(c, f.bmin, 12) == 0 && memcmp(e, f.extent, 12) == 0;
+}
+
+static std::unique_ptr<Partition> adopt_node(AdoptCtx& A, uint64_t idx, const std::vector<BoxedPrim>& list, int axis,
+                                             const BBox& bbox, uint64_t depth) {
+    if (!A.err.empty()) return nullptr;
+    if (idx >= A.n_nodes) { A.err = "node index out of range"; return nullptr; }
+    const FlatNode& f = A.nodes[idx];
+    if (!same_box(bbox, f)) { A.err = "node " + std::to_string(idx) + ": box differs from the oracle's"; return nullptr; }
+    std::unique_ptr<Partition> node(new Partition());
+    node->bbox = bbox;
+    A.st.nodes++;
+    if (depth > A.st.max_depth) A.st.max_depth = depth;
+    const bool check = list.size() <= A.verify_max;
+    SplitDecision d;
+    bool split = f.axis != 3;
+    if (check) {
+        const bool mine = find_splitting_plane(list, axis, appraise(list.size(), bbox), d, A.st, A.threads);
+        A.verified++;
+        if (mine != split) { A.err = "node " + std::to_string(idx) + ": leaf/interior decision differs"; return nullptr; }
+        if (split && (memcmp(&d.plane, &f.plane, 4) != 0 || (int)f.axis != axis)) {
+            A.err = "node " + std::to_string(idx) + ": split plane or axis differs";
+            return nullptr;
+        }
+    } else {
+        A.adopted++;
+        if (split) {
+            if ((int)f.axis != axis) { A.err = "node " + std::to_string(idx) + ": axis out of turn"; return nullptr; }
+            if (f.under >= A.n_nodes || f.over >= A.n_nodes) { A.err = "child index out of range"; return nullptr; }
+            d.plane = f.plane;
+            const FlatNode& u = A.nodes[f.under];
+            const FlatNode& o = A.nodes[f.over];
+            d.under_box = BBox{V3{u.bmin[0], u.bmin[1], u.bmin[2]}, V3{u.extent[0], u.extent[1], u.extent[2]}};
+            d.over_box = BBox{V3{o.bmin[0], o.bmin[1], o.bmin[2]}, V3{o.extent[0], o.extent[1], o.extent[2]}};
+        }
+    }
+    if (!split) {
+        if ((uint64_t)f.under + f.over > A.n_refs || f.over != list.size()) { A.err = "node " + std::to_string(idx) + ": leaf size differs"; return nullptr; }
+        for (size_t k = 0; k < list.size(); ++k)
+            if (A.refs[f.under + k] != list[k].prim) { A.err = "node " + std::to_string(idx) + ": leaf list differs"; return nullptr; }
+        node->leaf = true;
+        for (const BoxedPrim& bp : list) node->prims.push_back(bp.prim);
+        A.st.leaves++;
+        A.st.leaf_refs += list.size();
+        if (list.size() > A.st.max_leaf) A.st.max_leaf = list.size();
+        return node;
+    }
+    std::vector<BoxedPrim> over, under;
+    for (const BoxedPrim& bp : list) {  // split(), src/space_partition.rs:160-169
+        if (bp.box.max_corner().comp(axis) > d.plane) over.push_back(bp);
+        if (bp.box.corner.comp(axis) <= d.plane) under.push_back(bp);
+    }
+    const int next_axis = axis == AX ? AY : (axis == AY ? AZ : AX);
+    node->leaf = false;
+    node->axis = axis;
+    node->plane = d.plane;
+    node->over = adopt_node(A, f.over, over, next_axis, d.over_box, depth + 1);
+    node->under = adopt_node(A, f.under, under, next_axis, d.under_box, depth + 1);
+    if (!A.err.empty()) return nullptr;
+    return node;
+}
+
+void* oracle_scene_from_nff_with_tree(const char* text, size_t len, int use_phong, const void* nodes64, uint64_t n_nodes,
+                                      const uint32_t* refs, uint64_t n_refs, uint64_t verify_max, int threads,
+                                      uint64_t* verified_adopted2, char* err, size_t errlen) {
+    Handle* h = new Handle();
+    std::string e;
+    if (!read_nff(text, len, use_phong != 0, h->view, h->scene, e) || h->scene.primitives.empty() || n_nodes == 0) {
+        set_err(err, errlen, e.empty() ? "empty scene or partition" : e);
+        delete h;
+        return nullptr;
+    }
+    double t0 = now_ms();
+    Scene& sc = h->scene;
+    std::vector<BoxedPrim> boxed;  // src/space_partition.rs:206-216
+    BBox total = sc.primitives[0].shape.bounding_box();
+    boxed.push_back(BoxedPrim{0, total});
+    for (uint32_t i = 1; i < sc.primitives.size(); ++i) {
+        BBox b = sc.primitives[i].shape.bounding_box();
+        total = total.expand_to_fit(b);
+        boxed.push_back(BoxedPrim{i, b});
+    }
+    AdoptCtx A;
+    A.nodes = (const FlatNode*)nodes64; A.n_nodes = n_nodes; A.refs = refs; A.n_refs = n_refs;
+    A.verify_max = verify_max; A.threads = threads < 1 ? 1 : threads;
+    sc.partition = adopt_node(A, 0, boxed, AX, total, 0);
+    if (!A.err.empty() || !sc.partition) {
+        set_err(err, errlen, "partition not adopted: " + A.err);
+        delete h;
+        return nullptr;
+    }
+    sc.build_stats = A.st;
+    if (verified_adopted2) { verified_adopted2[0] = A.verified; verified_adopted2[1] = A.adopted; }
+    h->build_ms = now_ms() - t0;
+    return h;
+}
+
 void oracle_scene_free(void* hp) { delete (Handle*)hp; }
 
 int oracle_scene_info(void* hp, OracleInfo* o) {

@@ -4,7 +4,9 @@
 #include "ref_scene.h"
 
 #include <atomic>
+#include <cstring>
 #include <stdexcept>
+#include <string>
 #include <thread>
 
 namespace ref {
@@ -69,16 +71,22 @@ bool find_splitting_plane(const std::vector<BoxedPrim>& list, int axis, float no
 
 // reference src/space_partition.rs:223-258 (+ split :151-172, advance :174-180)
 std::unique_ptr<Partition> build_partition(const std::vector<BoxedPrim>& list, int axis, const BBox& bbox,
-                                           BuildStats& st, uint64_t depth, int threads) {
+                                           BuildStats& st, uint64_t depth, int threads, const SameListCall* up) {
     // The reference recursion has no depth bound and does not terminate on some
     // inputs: when the chosen plane is the largest min corner on the axis, split()
     // (:163-166) puts every primitive in `under` again while appraise_split (:111)
     // boxed one fewer, and the same decision can repeat on all three axes forever
     // (the reference then overflows its stack).  Such scenes have no reference
-    // output; report them instead of recursing.
-    if (depth > MAX_BUILD_DEPTH)
-        throw std::runtime_error("space partition recursion does not terminate on this scene "
-                                 "(the reference overflows its stack here)");
+    // output; report them instead of recursing.  Proof of non-termination, not a depth
+    // guess: this function depends on (list, axis, bbox) alone, so a call that has the
+    // arguments of an enclosing call repeats its decisions and meets itself again.  `up`
+    // chains the enclosing calls whose list had this length -- a child's list is a
+    // sub-sequence of its parent's, so those had this very list.
+    for (const SameListCall* a = up; a; a = a->up)
+        if (a->axis == axis && std::memcmp(&a->bbox, &bbox, sizeof(BBox)) == 0)
+            throw std::runtime_error("space partition recursion does not terminate on this scene: a call at depth " +
+                                     std::to_string(depth) + " has the list, axis and box of an enclosing call "
+                                     "(the reference overflows its stack here)");
     std::unique_ptr<Partition> node(new Partition());
     node->bbox = bbox;
     st.nodes++;
@@ -105,8 +113,9 @@ std::unique_ptr<Partition> build_partition(const std::vector<BoxedPrim>& list, i
     node->leaf = false;
     node->axis = axis;
     node->plane = d.plane;
-    node->over = build_partition(over, next_axis, d.over_box, st, depth + 1, threads);
-    node->under = build_partition(under, next_axis, d.under_box, st, depth + 1, threads);
+    const SameListCall me{axis, bbox, up};
+    node->over = build_partition(over, next_axis, d.over_box, st, depth + 1, threads, over.size() == list.size() ? &me : nullptr);
+    node->under = build_partition(under, next_axis, d.under_box, st, depth + 1, threads, under.size() == list.size() ? &me : nullptr);
     return node;
 }
 
@@ -129,7 +138,7 @@ void Scene::build_space_partition(int threads) {
         total = total.expand_to_fit(b);
         boxed.push_back(BoxedPrim{i, b});
     }
-    partition = build_partition(boxed, AX, total, build_stats, 0, threads);
+    partition = build_partition(boxed, AX, total, build_stats, 0, threads, nullptr);
 }
 
 // reference src/space_partition.rs:268-289 (node), :292-346 (interior), :348-385 (leaf)

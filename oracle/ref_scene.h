@@ -96,7 +96,13 @@ struct BuildStats {
     uint64_t nodes = 0, leaves = 0, leaf_refs = 0, max_depth = 0, max_leaf = 0, split_attempts = 0;
 };
 
-constexpr uint64_t MAX_BUILD_DEPTH = 512;
+// An enclosing call of build_partition whose list is the current call's list: (list, axis, bbox)
+// seen twice on one path proves that the reference's recursion never returns.
+struct SameListCall {
+    int axis;
+    BBox bbox;
+    const SameListCall* up;
+};
 
 // :184-193
 static inline float appraise(size_t count, const BBox& b) { return b.surface_area() * (float)count; }
@@ -145,7 +151,8 @@ bool find_splitting_plane(const std::vector<BoxedPrim>& list, int axis, float no
 
 // :223-258
 std::unique_ptr<Partition> build_partition(const std::vector<BoxedPrim>& list, int axis, const BBox& bbox,
-                                           BuildStats& st, uint64_t depth, int threads);
+                                           BuildStats& st, uint64_t depth, int threads,
+                                           const SameListCall* up = nullptr);
 
 // ---------------------------------------------------------------------------
 // Scene (src/scene.rs)

@@ -101,13 +101,26 @@ Box polygon_box(const rt_vertex* v, uint32_t n) {  // src/polygon.rs:11-56
     return b;
 }
 
+// What from_boxed_primitives (src/space_partition.rs:223) is called with, less the list.
+struct CallState {
+    uint32_t axis;
+    Box box;
+};
+
 struct Work {
     uint32_t node;
     uint32_t axis;
     uint32_t depth;
     Box box;
     std::vector<uint32_t> list;  // primitive ids, builder list order
+    // Ancestors' calls that had this very list (consecutive ones up the path: a child's list is a
+    // sub-sequence of its parent's, so equal length means equal list).
+    std::vector<CallState> same_list;
 };
+
+inline bool same_call(const CallState& a, uint32_t axis, const Box& box) {
+    return a.axis == axis && memcmp(&a.box, &box, sizeof(Box)) == 0;
+}
 
 // Cost of splitting `list` at `plane` (src/space_partition.rs:100-149); optionally
 // returns the two boxes.
@@ -262,13 +275,6 @@ int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err, const Sp
             continue;
         }
 
-        if (w.depth + 1 > 512) {
-            err = "space partition construction does not terminate on this scene: the reference's split() "
-                  "(src/space_partition.rs:163-166) keeps returning the same primitive list (it overflows its "
-                  "stack on such input)";
-            return RT_ERR_BUILD;
-        }
-
         Work wu, wo;
         for (uint32_t p : w.list) {  // split(), :160-169
             const Box& b = boxes[p];
@@ -276,6 +282,27 @@ int build_tree(const rt_scene_desc& d, HostTree& out, std::string& err, const Sp
             if (b.c[axis] <= plane) wu.list.push_back(p);
         }
         const uint32_t next_axis = (w.axis + 1) % 3;
+        // The reference recursion has no depth bound, and from_boxed_primitives is a function of its
+        // arguments alone: a call whose (list, axis, box) equals an ancestor's repeats that
+        // ancestor's decisions, reaches the same call again and never returns (the reference
+        // overflows its stack).  That is decided here exactly: a child whose list is as long as the
+        // parent's has the parent's list, and is compared with the chain of calls that had it.  The
+        // test is also complete -- with the list unchanged the plane is the same for an axis whatever
+        // the box, so a path either shortens its list or revisits a call within seven levels.
+        for (Work* c : {&wu, &wo}) {
+            const Box& cb = c == &wu ? under_box : over_box;
+            if (c->list.size() != n) continue;
+            c->same_list = w.same_list;
+            c->same_list.push_back(CallState{w.axis, w.box});
+            for (const CallState& a : c->same_list)
+                if (same_call(a, next_axis, cb)) {
+                    err = "space partition construction does not terminate on this scene: at depth " +
+                          std::to_string(w.depth + 1) + " the reference's split() (src/space_partition.rs:163-166) hands a "
+                          "list of " + std::to_string(n) + " primitives, axis and box to from_boxed_primitives that an "
+                          "enclosing call already had (it overflows its stack on such input)";
+                    return RT_ERR_BUILD;
+                }
+        }
         const uint32_t me = w.node;
         const uint32_t iu = make_node(under_box, me, w.depth + 1);
         const uint32_t io = make_node(over_box, me, w.depth + 1);

@@ -21,6 +21,7 @@ CASES = [
     ("balls", dict(size=4), 3840, 2160, 8, 6),                # the headline: 7,381 spheres, deep reflection
     ("lathe", dict(nu=96, nv=48), 1920, 1080, 5, 6),          # teapot-class polygon mesh with vertex normals
     ("rings", dict(size=4), 3840, 2160, 8, 3),                # cones / cylinders, refraction
+    ("rings", dict(size=6), 3840, 2160, 8, 3),                # 1,824 primitives (size 5 is a scene the reference's builder never finishes)
     ("mount", dict(size=6, lights=8), 3840, 2160, 8, 3),      # 8k polygons, refractive spheres, many lights
     ("tetra", dict(size=6), 3840, 2160, 5, 6),
 ]
@@ -49,3 +50,70 @@ def test_full_size_properties(rtamd, oracle, spd, gpu_ctx, gen, kw, w, h, depth,
     sel = slice(step // 2, None, step)
     assert np.array_equal(bits(cf[sel]), bits(of[sel]))
     assert np.array_equal(cu[sel], ou[sel])
+
+
+# ---- the largest configuration: mount size 8 (131,072 triangles + 4 refractive spheres, 8 point
+# lights) and tetra at 7680 x 4320, depth 8.  A whole frame of either is far beyond what the CPU oracle
+# renders in test time, and so is the oracle's own O(n^2) construction of the mount tree; what is
+# checked instead:
+#   * the oracle adopts the library's flat tree only after re-deriving every node's primitive list and
+#     box itself and recomputing the decision of every node of up to 2,048 primitives;
+#   * rows spread over the frame equal the oracle's render of those rows, bit for bit;
+#   * on 1/64 of the image (interleaved 8x8 tiles) the culled walk equals the exhaustive one, the
+#     reference's own leaf walk, bit for bit and ray for ray;
+#   * the ray-count identities of a frame hold, and the 64 tile shares' primary rays add up to the image.
+def test_mount_8_with_8_lights_at_8k(rtamd, oracle, spd, gpu_ctx):
+    w, h, depth = 7680, 4320, 8
+    text = spd.mount(8, 8, w, h)
+    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=16)
+    assert sc.tree_info.n_leaf_refs > 131072 and text.count("\nl ") == 8
+    cf, cu, cst = sc.render(rtamd.RenderOptions(max_depth=depth), w, h)
+    c = cst.as_dict()
+    assert c["rays_primary"] == w * h and c["rays_shadow"] % 8 == 0
+    assert cst.ray_nodes == c["rays_primary"] + c["rays_reflect"] + c["rays_refract"]
+    assert c["rays_refract"] > 0 and cst.levels > 2  # the glass spheres are in view
+    # culled == exhaustive on one tile share of 64
+    tf, tu, tst = sc.render(rtamd.RenderOptions(max_depth=depth, tile_rank=37, tile_count=64), w, h)
+    ef, eu, est = sc.render(rtamd.RenderOptions(max_depth=depth, tile_rank=37, tile_count=64, exhaustive_leaves=True), w, h)
+    assert np.array_equal(bits(tf), bits(ef)) and np.array_equal(tu, eu)
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
+        assert tst.as_dict()[k] == est.as_dict()[k], k
+    assert tst.rays_primary == rtamd.tile_pixels(w, h, 37, 64)  # (w and h are multiples of 8: no padding slots)
+    # that share is the whole frame's pixels
+    ys, xs = np.meshgrid(np.arange(0, h, 97), np.arange(0, w, 89), indexing="ij")
+    for y, x in zip(ys.ravel()[:4000], xs.ravel()[:4000]):
+        slot, rank = rtamd.tile_slot(w, h, 64, int(x), int(y))
+        if rank == 37:
+            assert np.array_equal(bits(tf[slot]), bits(cf[y, x]))
+    del tf, tu, ef, eu
+    # rows of the frame from the oracle, on the library's tree after the oracle has checked it
+    nodes, refs = sc.tree()
+    o = oracle.OracleScene(text, build_threads=16, tree=(nodes, refs), verify_max=2048)
+    assert o.tree_checked[0] > 10 * o.tree_checked[1] and o.info.max_leaf == sc.tree_info.max_leaf
+    rows = (701, 2160, 3517)  # sky and far terrain, the glass spheres, near terrain
+    for r in rows:
+        of, ou, octr, _ = o.render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, row_start=r, row_step=h, threads=16)
+        assert np.array_equal(bits(cf[r]), bits(of[r])), r
+        assert np.array_equal(cu[r], ou[r]), r
+
+
+def test_tetra_at_8k(rtamd, oracle, spd, gpu_ctx):
+    """tetra at the largest size on which the reference's construction ends: size 7 (and 8) hand a
+    call its enclosing call's arguments again, which is refused with the proof, not rendered."""
+    w, h, depth = 7680, 4320, 8
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.Scene.from_nff(gpu_ctx, spd.tetra(7, 64, 64), build_threads=16)
+    assert e.value.code == rtamd.RT_ERR_BUILD and "an enclosing call already had" in str(e.value)
+    text = spd.tetra(6, w, h)
+    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=16)
+    cf, cu, cst = sc.render(rtamd.RenderOptions(max_depth=depth), w, h)
+    ef, eu, est = sc.render(rtamd.RenderOptions(max_depth=depth, exhaustive_leaves=True), w, h)
+    assert np.array_equal(bits(cf), bits(ef)) and np.array_equal(cu, eu)
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
+        assert cst.as_dict()[k] == est.as_dict()[k], k
+    assert cst.rays_primary == w * h
+    del ef, eu
+    o = oracle.OracleScene(text, build_threads=16)
+    for r in (1100, 2160, 3300):
+        of, ou, _, _ = o.render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, row_start=r, row_step=h, threads=16)
+        assert np.array_equal(bits(cf[r]), bits(of[r])) and np.array_equal(cu[r], ou[r]), r
