@@ -137,12 +137,11 @@ def main():
     opt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world)
 
     stream = torch.cuda.current_stream().cuda_stream
-    image = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
-    if world > 1:
-        stride = rtamd.tile_pixels_max(W, H, world)
-        mine = torch.zeros((stride, 3), dtype=torch.uint8, device="cuda")
-        gathered = torch.zeros((world, stride, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
-        parts = list(gathered.unbind(0)) if rank == 0 else None
+    if world > 1:  # every rank's compact tile buffer, gathered to rank 0 and de-interleaved there
+        tg = rtamd.TileGather(W, H, rank, world, "cuda", ctx)
+        image, mine = tg.image, tg.mine
+    else:
+        image = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
 
     # Frames are queued without waiting for the previous one (two or four in flight, whichever measured faster): the small
     # launches that end a frame run beside the big ones that start the next.  Each frame's image
@@ -156,9 +155,7 @@ def main():
         target = image if world == 1 else mine
         pending.append(scene.render_device_begin(opt, None, target.data_ptr(), stream))
         if world > 1:
-            dist.gather(mine, parts, dst=0)
-            if rank == 0:
-                ctx.deinterleave(W, H, world, stride, 1, gathered.data_ptr(), image.data_ptr(), stream)
+            tg.gather(stream)
 
     def drain():
         while pending:

@@ -12,10 +12,14 @@
  * exception crosses this boundary; rt_last_error() gives the message of the last
  * failure on a context.  The caller owns every buffer it passes in; the library
  * owns device memory behind the opaque handles.  One host thread per context.
- * One context drives one GPU; a multi-GPU job is one process (and context) per
- * GPU, each rendering its share of interleaved tiles (rt_options.tile_rank /
- * tile_count), with the host gathering the tile buffers (RCCL) and calling
- * rt_deinterleave_device on the root rank.
+ * Several GPUs, two ways.  (1) One process per GPU, each with a one-device context
+ * rendering its share of interleaved tiles (rt_options.tile_rank / tile_count), the
+ * host gathering the tile buffers (RCCL) and calling rt_deinterleave_device on the
+ * root rank.  (2) One process, one context over N devices (rt_context_create with
+ * n_devices > 1): rt_scene_create puts a copy of the scene on every device, and
+ * rt_render / rt_render_device trace every device's share at once, gather the tile
+ * buffers into the first device over the GPUs' links (peer copies) and de-interleave
+ * there -- the caller sees one image, as from one GPU.
  */
 #ifndef RTAMD_H
 #define RTAMD_H
@@ -130,6 +134,8 @@ typedef struct rt_options {
     uint32_t exhaustive_leaves; /* nonzero: test every primitive of every visited leaf as the reference
                                 does; 0 (default): big leaves skip groups of spheres whose bounding
                                 sphere proves that the reference's test rejects them -- same image */
+    uint32_t compact_tiles;  /* nonzero: write the compact tile buffer (rt_tile_pixels slots) even when
+                                tile_count is 0 or 1, so that one rank runs the code path of many */
 } rt_options;
 
 typedef struct rt_stats {
@@ -161,7 +167,15 @@ typedef struct rt_context rt_context;
 typedef struct rt_scene rt_scene;
 
 /* ---- lifetime ---- */
+/* n_devices >= 1 device ordinals (NULL = 0, 1, ...); the first is the root device, where whole
+ * images are put together and where device output pointers must live.  A context over several
+ * devices serves rt_scene_create, rt_render and rt_render_device (with tile_count <= 1: it does
+ * the tiling itself); the frame-after-frame, static-workspace and diagnostic entry points, and
+ * collect_work, are for one-device contexts.  *out is set even on failure, so that
+ * rt_last_error can be read; destroy it afterwards. */
 int rt_context_create(int n_devices, const int* device_ids, rt_context** out);
+/* Devices the context renders on. */
+uint32_t rt_context_device_count(const rt_context* ctx);
 void rt_context_destroy(rt_context* ctx);
 const char* rt_last_error(const rt_context* ctx);
 

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = (
     "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
-    "rt_debug_bound", "rt_frames_in_flight", "rt_context_set_workspace_limit", "rt_render_device_static",
+    "rt_debug_bound", "rt_frames_in_flight", "rt_context_set_workspace_limit", "rt_render_device_static", "rt_context_device_count",
 )
 
 
@@ -113,7 +113,7 @@ class rt_scene_desc(C.Structure):
 class rt_options(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("min_contribution", C.c_float), ("fp_mode", C.c_uint32),
                 ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32), ("collect_work", C.c_uint32),
-                ("exhaustive_leaves", C.c_uint32)]
+                ("exhaustive_leaves", C.c_uint32), ("compact_tiles", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
@@ -204,6 +204,8 @@ def lib():
     L.rt_frames_in_flight.argtypes = [vp]
     L.rt_frames_in_flight.restype = C.c_uint32
     L.rt_context_set_workspace_limit.argtypes = [vp, C.c_uint64]
+    L.rt_context_device_count.argtypes = [vp]
+    L.rt_context_device_count.restype = C.c_uint32
     L.rt_debug_intersect.argtypes = [vp, vp, C.c_uint32, C.c_uint64] + [vp] * 7
     L.rt_debug_eval.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
     _lib = L
@@ -297,12 +299,14 @@ class ParsedScene:
 
 
 class Context:
-    """One GPU (rt_context)."""
+    """One GPU, or several driven from this one process (rt_context): `device` is an ordinal or a
+    list of ordinals, the first being the root device where whole images are put together."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0):
         h = C.c_void_p()
-        ids = (C.c_int * 1)(device)
-        rc = lib().rt_context_create(1, ids, C.byref(h))
+        devices = [int(device)] if isinstance(device, int) else [int(d) for d in device]
+        ids = (C.c_int * len(devices))(*devices)
+        rc = lib().rt_context_create(len(devices), ids, C.byref(h))
         self._h = h
         if rc != RT_OK:
             msg = lib().rt_last_error(h).decode() if h else "context allocation failed"
@@ -310,7 +314,8 @@ class Context:
                 lib().rt_context_destroy(h)
             self._h = None
             raise RtError(rc, msg)
-        self.device = device
+        self.device = devices[0]
+        self.devices = devices
 
     @property
     def frames_in_flight(self) -> int:
@@ -356,10 +361,11 @@ class RenderOptions:
     tile_count: int = 1
     collect_work: bool = False
     exhaustive_leaves: bool = False  # True: no bounding-sphere culling inside big leaves (same image, slower)
+    compact_tiles: bool = False      # True: compact tile buffer as output even for a single rank
 
     def c(self):
         return rt_options(self.max_depth, self.min_contribution, self.fp_mode, self.tile_rank, self.tile_count,
-                          int(self.collect_work), int(self.exhaustive_leaves))
+                          int(self.collect_work), int(self.exhaustive_leaves), int(self.compact_tiles))
 
 
 class Scene:
@@ -412,7 +418,7 @@ class Scene:
         buffers [n_slots, 3] of this rank instead."""
         opt = opt or RenderOptions()
         v = self.view(width, height)
-        if opt.tile_count > 1:
+        if opt.tile_count > 1 or opt.compact_tiles:
             n = lib().rt_tile_pixels(v.width, v.height, opt.tile_rank, opt.tile_count)
             shape = (n, 3)
         else:
@@ -552,3 +558,41 @@ def deinterleave_host(width, height, count, gathered: np.ndarray):
     if rc != RT_OK:
         raise RtError(rc, "rt_deinterleave_host")
     return out
+
+
+class TileGather:
+    """The exchange step of a frame rendered by one process per GPU (torch.distributed): every rank
+    has traced its interleaved 8x8 tiles into the compact buffer `mine`; gather() brings the buffers
+    to rank 0 -- one collective, RCCL over the GPUs' links with the nccl backend -- and rank 0
+    de-interleaves them into the row-major `image`.  On CPU tensors (gloo) the same calls run with
+    the host de-interleave, which is how the path is tested without several GPUs."""
+
+    def __init__(self, width, height, rank, world, device, ctx: Optional["Context"] = None, group=None):
+        import torch
+        self.width, self.height, self.rank, self.world, self.ctx, self.group = width, height, rank, world, ctx, group
+        self.stride = tile_pixels_max(width, height, world)
+        self.mine = torch.zeros((self.stride, 3), dtype=torch.uint8, device=device)
+        self.gathered = torch.zeros((world, self.stride, 3), dtype=torch.uint8, device=device) if rank == 0 else None
+        self.parts = list(self.gathered.unbind(0)) if rank == 0 else None
+        self.image = torch.zeros((height, width, 3), dtype=torch.uint8, device=device) if rank == 0 else None
+        if self.mine.is_cuda and ctx is None:
+            raise ValueError("device tensors need the rank's Context for the de-interleave kernel")
+
+    def options(self, **kw) -> "RenderOptions":
+        """Render options of this rank's share (compact tile output also when there is one rank)."""
+        return RenderOptions(tile_rank=self.rank, tile_count=self.world, compact_tiles=True, **kw)
+
+    def gather(self, stream=None):
+        """Queued behind the frame that fills `mine` (same stream); rank 0's `image` is complete when
+        the stream has run."""
+        import torch.distributed as dist
+        dist.gather(self.mine, self.parts, dst=0, group=self.group)
+        if self.rank == 0:
+            if self.mine.is_cuda:
+                self.ctx.deinterleave(self.width, self.height, self.world, self.stride, 1, self.gathered.data_ptr(),
+                                      self.image.data_ptr(), stream)
+            else:
+                rc = lib().rt_deinterleave_host(self.width, self.height, self.world, self.stride, 1,
+                                                self.gathered.data_ptr(), self.image.data_ptr())
+                if rc != RT_OK:
+                    raise RtError(rc, "rt_deinterleave_host")

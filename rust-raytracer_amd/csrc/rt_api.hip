@@ -118,6 +118,14 @@ struct rt_context {
     FrameSlot slot[RT_MAX_FRAME_SLOTS];  // all set up, the first n_slots in use
     uint32_t n_slots = RT_MAX_FRAME_SLOTS;
     uint32_t next_slot = 0;
+    // A context over several devices is this context (the root: rank 0, where images are put
+    // together) plus one one-device context per further rank.  Every rank keeps its own compact
+    // tile buffers, a stream for its frame and the copy to the root, and the event that ends both.
+    std::vector<rt_context*> peers;
+    DevBuf<float> tile_f32, gathered_f32;
+    DevBuf<uint8_t> tile_u8, gathered_u8;
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t ev_gather = nullptr;
     FrameSlot fixed_slot;                // rt_render_device_static: its workspace is a share of `scratch`
     unsigned char* scratch_ptr = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress)
     // Pool sizes every slot is brought to before a frame: the largest any finished frame needed,
@@ -136,6 +144,10 @@ struct rt_context {
 
 struct rt_scene {
     rt_context* ctx = nullptr;
+    std::vector<rt_scene*> peer_scenes;  // the copies on the context's further devices
+    ~rt_scene() {
+        for (rt_scene* p : peer_scenes) delete p;
+    }
     SceneData data;
     HostTree tree;
     DevBuf<uint4> nodes, cone_items, poly_items;
@@ -157,8 +169,11 @@ int fail(rt_context* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// (The launchers report through hipGetLastError, which also returns what an earlier failed call of
+// anybody in this thread left behind -- another library probing device ordinals, say: cleared first.)
 #define RT_HIP(ctx, call)                                                                              \
     do {                                                                                               \
+        (void)hipGetLastError();                                                                       \
         hipError_t e_ = (call);                                                                        \
         if (e_ != hipSuccess)                                                                          \
             return fail(ctx, RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
@@ -278,13 +293,11 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
     *out = nullptr;
     rt_context* ctx = new rt_context();
     *out = ctx;  // returned even on failure so the message can be read; destroy it afterwards
-    if (n_devices != 1)
-        return fail(ctx, RT_ERR_UNSUPPORTED,
-                    "a context drives one GPU: create one context per process and GPU and partition the image "
-                    "with rt_options.tile_rank / tile_count");
+    if (n_devices < 1 || n_devices > MAX_DEVICES) return fail(ctx, RT_ERR_INVALID, "n_devices out of range");
     int count = 0;
     RT_HIP(ctx, hipGetDeviceCount(&count));
     ctx->device = device_ids ? device_ids[0] : 0;
+    if (ctx->device >= MAX_DEVICES) return fail(ctx, RT_ERR_INVALID, "device id out of range");
     if (ctx->device < 0 || ctx->device >= count) return fail(ctx, RT_ERR_INVALID, "device id out of range");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipDeviceProp_t prop;
@@ -318,13 +331,38 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         int rc = prepare_kernels(ctx);
         if (rc != RT_OK) return rc;
     }
+    RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
+    RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gather, hipEventDisableTiming));
+    // further devices: one one-device context each; their tile buffers are copied into this device
+    for (int r = 1; r < n_devices; ++r) {
+        const int id = device_ids ? device_ids[r] : r;
+        rt_context* peer = nullptr;
+        const int rc = rt_context_create(1, &id, &peer);
+        if (peer) ctx->peers.push_back(peer);
+        if (rc != RT_OK) return fail(ctx, rc, std::string("device ") + std::to_string(id) + ": " + (peer ? peer->err : "no context"));
+        if (id != ctx->device) {  // direct copies over the GPUs' links where the platform allows them
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, id, ctx->device) == hipSuccess && can) {
+                (void)hipSetDevice(id);
+                (void)hipDeviceEnablePeerAccess(ctx->device, 0);
+                (void)hipGetLastError();  // (already enabled is not an error here)
+            }
+        }
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
     return RT_OK;
 }
 
+extern "C" uint32_t rt_context_device_count(const rt_context* ctx) { return ctx ? 1u + (uint32_t)ctx->peers.size() : 0u; }
+
 extern "C" void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
+    for (rt_context* p : ctx->peers) rt_context_destroy(p);
+    (void)hipSetDevice(ctx->device);
     for (FrameSlot& f : ctx->slot) teardown_slot(f);
     teardown_slot(ctx->fixed_slot);
+    if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
+    if (ctx->gather_stream) (void)hipStreamDestroy(ctx->gather_stream);
     delete ctx;
 }
 
@@ -553,6 +591,19 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     memcpy(d.bg, sd.background, sizeof(d.bg));
     if (d.stack_depth > RT_STACK_RING + RT_STACK_DEEP)
         return fail(ctx, RT_ERR_UNSUPPORTED, "space partition deeper than the device traversal stack (64 levels)");
+    // a copy of the scene, with this partition, on each further device of the context
+    for (rt_context* peer : ctx->peers) {
+        rt_scene_desc pd = sc->data.desc;
+        pd.n_nodes = (uint32_t)sc->tree.nodes.size();
+        pd.n_leaf_refs = (uint32_t)sc->tree.refs.size();
+        pd.nodes = sc->tree.nodes.data();
+        pd.leaf_refs = sc->tree.refs.data();
+        rt_scene* ps = nullptr;
+        rc = rt_scene_create(peer, &pd, &ps);
+        if (rc != RT_OK) return fail(ctx, rc, "device " + std::to_string(peer->device) + ": " + peer->err);
+        sc->peer_scenes.push_back(ps);
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
     *out = sc.release();
     return RT_OK;
 }
@@ -644,6 +695,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.tiles_x = grid.tiles_x;
     A.tile_rank = opt->tile_rank;
     A.tile_count = tile_count;
+    A.compact = (tile_count > 1 || opt->compact_tiles != 0) ? 1u : 0u;
     A.n_slots = n_slots;
     A.max_depth = opt->max_depth;
     A.min_contribution = opt->min_contribution;
@@ -864,7 +916,10 @@ int check_frame_args(rt_context* ctx, const rt_scene* scene, const rt_view* view
 
 }  // namespace
 
-extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+namespace {
+
+// (rt_render_device_begin, also for one rank of a context over several devices)
+int begin_frame(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                                       void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out) {
     if (!ticket_out) return fail(ctx, RT_ERR_INVALID, "null argument");
     int rc = check_frame_args(ctx, scene, view, opt);
@@ -917,6 +972,14 @@ extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, co
     return RT_OK;
 }
 
+}  // namespace
+
+extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
+                                      void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out) {
+    if (ctx && !ctx->peers.empty()) return fail(ctx, RT_ERR_UNSUPPORTED, "frames in flight are for one-device contexts");
+    return begin_frame(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, ticket_out);
+}
+
 extern "C" int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out) {
     if (!ctx || ticket >= ctx->n_slots) return fail(ctx, RT_ERR_INVALID, "bad ticket");
     FrameSlot& f = ctx->slot[ticket];
@@ -946,6 +1009,7 @@ extern "C" int rt_render_device_static(rt_context* ctx, const rt_scene* scene, c
                                        void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {
     int rc = check_frame_args(ctx, scene, view, opt);
     if (rc != RT_OK) return rc;
+    if (!ctx->peers.empty()) return fail(ctx, RT_ERR_UNSUPPORTED, "the static workspace is for one-device contexts");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     FrameSlot& f = ctx->fixed_slot;
     if (f.busy || !ctx->scratch_ptr || !ctx->kernels_ready) return fail(ctx, RT_ERR_INVALID, "context not ready");
@@ -1000,8 +1064,118 @@ extern "C" int rt_render_device_static(rt_context* ctx, const rt_scene* scene, c
 
 extern "C" uint32_t rt_frames_in_flight(const rt_context* ctx) { return ctx ? ctx->n_slots : 0; }
 
+namespace {
+
+// One frame on a context over several devices: every rank (device) traces its interleaved 8x8
+// tiles into a compact buffer (pixels are independent, src/render.rs:104-112; every device holds
+// the whole scene), ranks 1.. copy theirs into the root device's gathered buffer over the GPUs'
+// links, and the root de-interleaves into the caller's image.  All ranks' frames are queued
+// before any is waited for.
+int render_multi(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt, void* d_f32, void* d_u8,
+                 void* stream, rt_stats* stats_out) {
+    int rc = check_frame_args(ctx, scene, view, opt);
+    if (rc != RT_OK) return rc;
+    const uint32_t n = 1u + (uint32_t)ctx->peers.size();
+    if ((opt->tile_count > 1) || opt->compact_tiles || opt->collect_work)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "a context over several devices tiles the image itself and keeps no work counters");
+    if (scene->peer_scenes.size() + 1 != n) return fail(ctx, RT_ERR_INVALID, "scene was not created on this context");
+    const uint32_t W = view->width, H = view->height;
+    const size_t stride = (size_t)rt_tile_pixels_max(W, H, n);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (d_f32 && ctx->gathered_f32.n < stride * n * 3) RT_HIP(ctx, ctx->gathered_f32.alloc(stride * n * 3));
+    if (d_u8 && ctx->gathered_u8.n < stride * n * 3) RT_HIP(ctx, ctx->gathered_u8.alloc(stride * n * 3));
+    uint32_t ticket[MAX_DEVICES];
+    uint32_t begun = 0;
+    auto rank_ctx = [&](uint32_t r) { return r == 0 ? ctx : ctx->peers[r - 1]; };
+    std::string err;
+    for (uint32_t r = 0; r < n && rc == RT_OK; ++r) {
+        rt_context* c = rank_ctx(r);
+        const rt_scene* sc = r == 0 ? scene : scene->peer_scenes[r - 1];
+        hipError_t e = hipSetDevice(c->device);
+        const size_t mine = (size_t)rt_tile_pixels(W, H, r, n) * 3;
+        float* pf = nullptr;
+        uint8_t* pu = nullptr;
+        if (r == 0) {  // the root's share goes straight into its place
+            pf = d_f32 ? ctx->gathered_f32.p : nullptr;
+            pu = d_u8 ? ctx->gathered_u8.p : nullptr;
+        } else {
+            if (e == hipSuccess && d_f32 && c->tile_f32.n < stride * 3) e = c->tile_f32.alloc(stride * 3);
+            if (e == hipSuccess && d_u8 && c->tile_u8.n < stride * 3) e = c->tile_u8.alloc(stride * 3);
+            pf = d_f32 ? c->tile_f32.p : nullptr;
+            pu = d_u8 ? c->tile_u8.p : nullptr;
+        }
+        if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); break; }
+        rt_options o = *opt;
+        o.tile_rank = r;
+        o.tile_count = n;
+        rc = begin_frame(c, sc, view, &o, pf, pu, c->gather_stream, &ticket[r]);
+        if (rc != RT_OK) { err = "device " + std::to_string(c->device) + ": " + c->err; break; }
+        ++begun;
+        if (r > 0) {
+            if (d_f32) e = hipMemcpyPeerAsync(ctx->gathered_f32.p + (size_t)r * stride * 3, ctx->device, pf, c->device,
+                                              mine * sizeof(float), c->gather_stream);
+            if (e == hipSuccess && d_u8)
+                e = hipMemcpyPeerAsync(ctx->gathered_u8.p + (size_t)r * stride * 3, ctx->device, pu, c->device, mine, c->gather_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(c->ev_gather, c->gather_stream);
+        if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); }
+    }
+    (void)hipSetDevice(ctx->device);
+    if (rc == RT_OK) {
+        hipError_t e = hipSuccess;
+        for (uint32_t r = 0; r < n && e == hipSuccess; ++r) e = hipStreamWaitEvent((hipStream_t)stream, rank_ctx(r)->ev_gather, 0);
+        if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); }
+        if (rc == RT_OK && d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, ctx->gathered_f32.p, d_f32, stream);
+        if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, ctx->gathered_u8.p, d_u8, stream);
+        if (rc != RT_OK && err.empty()) err = ctx->err;
+    }
+    // every frame that was begun is ended, whatever happened since
+    rt_stats total;
+    memset(&total, 0, sizeof(total));
+    for (uint32_t r = 0; r < begun; ++r) {
+        rt_context* c = rank_ctx(r);
+        rt_stats st;
+        const int rc_end = rt_render_device_end(c, ticket[r], &st);
+        if (rc_end != RT_OK) {
+            if (rc == RT_OK) { rc = rc_end; err = "device " + std::to_string(c->device) + ": " + c->err; }
+            continue;
+        }
+        if (st.retries > 0 && r > 0 && rc == RT_OK) {
+            // the frame was run again after its copy to the root had been queued: copy again
+            (void)hipSetDevice(c->device);
+            const size_t mine = (size_t)rt_tile_pixels(W, H, r, n) * 3;
+            hipError_t e = hipSuccess;
+            if (d_f32) e = hipMemcpyPeer(ctx->gathered_f32.p + (size_t)r * stride * 3, ctx->device, c->tile_f32.p, c->device, mine * sizeof(float));
+            if (e == hipSuccess && d_u8) e = hipMemcpyPeer(ctx->gathered_u8.p + (size_t)r * stride * 3, ctx->device, c->tile_u8.p, c->device, mine);
+            if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); }
+            (void)hipSetDevice(ctx->device);
+            if (rc == RT_OK && d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, ctx->gathered_f32.p, d_f32, stream);
+            if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, ctx->gathered_u8.p, d_u8, stream);
+        } else if (st.retries > 0 && r == 0 && rc == RT_OK) {
+            if (d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, ctx->gathered_f32.p, d_f32, stream);
+            if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, ctx->gathered_u8.p, d_u8, stream);
+        }
+        total.rays_primary += st.rays_primary; total.rays_shadow += st.rays_shadow;
+        total.rays_reflect += st.rays_reflect; total.rays_refract += st.rays_refract;
+        total.ray_nodes += st.ray_nodes;
+        total.levels = std::max(total.levels, st.levels);
+        total.retries = std::max(total.retries, st.retries);
+        total.ms_trace = std::max(total.ms_trace, st.ms_trace);
+        total.ms_resolve = std::max(total.ms_resolve, st.ms_resolve);
+        total.ms_frame = std::max(total.ms_frame, st.ms_frame);
+    }
+    (void)hipSetDevice(ctx->device);
+    if (rc != RT_OK) return fail(ctx, rc, err);
+    RT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (stats_out) *stats_out = total;
+    return RT_OK;
+}
+
+}  // namespace
+
 extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                                 void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {
+    if (ctx && !ctx->peers.empty()) return render_multi(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, stats_out);
     uint32_t ticket = 0;
     int rc = rt_render_device_begin(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, &ticket);
     if (rc != RT_OK) return rc;
@@ -1014,13 +1188,14 @@ extern "C" int rt_render(rt_context* ctx, const rt_scene* scene, const rt_view* 
     const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
     if (opt->tile_rank >= tile_count) return fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_count");
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t px = tile_count == 1 ? (size_t)view->width * view->height
-                                      : (size_t)rt_tile_pixels(view->width, view->height, opt->tile_rank, tile_count);
+    const bool compact = tile_count > 1 || opt->compact_tiles != 0;
+    const size_t px = !compact ? (size_t)view->width * view->height
+                               : (size_t)rt_tile_pixels(view->width, view->height, opt->tile_rank, tile_count);
     if (rgb_f32_out && ctx->out_f32.n < px * 3) RT_HIP(ctx, ctx->out_f32.alloc(px * 3));
     if (rgb_u8_out && ctx->out_u8.n < px * 3) RT_HIP(ctx, ctx->out_u8.alloc(px * 3));
     // padding slots of edge tiles are never written by the kernels: clear them
-    if (rgb_f32_out && tile_count > 1) RT_HIP(ctx, hipMemset(ctx->out_f32.p, 0, px * 3 * sizeof(float)));
-    if (rgb_u8_out && tile_count > 1) RT_HIP(ctx, hipMemset(ctx->out_u8.p, 0, px * 3));
+    if (rgb_f32_out && compact) RT_HIP(ctx, hipMemset(ctx->out_f32.p, 0, px * 3 * sizeof(float)));
+    if (rgb_u8_out && compact) RT_HIP(ctx, hipMemset(ctx->out_u8.p, 0, px * 3));
     rt_stats stats;
     int rc = rt_render_device(ctx, scene, view, opt, rgb_f32_out ? ctx->out_f32.p : nullptr,
                               rgb_u8_out ? ctx->out_u8.p : nullptr, nullptr, &stats);

@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(FrameArgs A, uint32_t leve
         }
         if (LEVEL0) {
             // whole image: row-major pixel index; tile-interleaved: the compact slot index
-            const uint64_t o = (A.tile_count > 1 ? (uint64_t)i : (uint64_t)py * A.width + px) * 3;
+            const uint64_t o = (A.compact != 0u ? (uint64_t)i : (uint64_t)py * A.width + px) * 3;
             if (A.out_f32) { A.out_f32[o] = col.x; A.out_f32[o + 1] = col.y; A.out_f32[o + 2] = col.z; }
             if (A.out_u8) {
                 A.out_u8[o] = (uint8_t)quantize_u8(col.x);

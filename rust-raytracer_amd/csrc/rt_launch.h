@@ -58,6 +58,7 @@ struct FrameArgs {
     uint32_t width, height;
     // interleaved tiles
     uint32_t tiles_x, tile_rank, tile_count;
+    uint32_t compact;  // outputs are this rank's compact tile buffer (always so when tile_count > 1)
     uint32_t n_slots;  // level-0 rays: 64 per local tile
     // integrator constants (reference src/scene.rs:8-9)
     uint32_t max_depth;

@@ -483,3 +483,69 @@ def test_two_frames_in_flight(rtamd, oracle, gpu_ctx):
     torch.cuda.synchronize()
     assert np.array_equal(snaps[0].cpu().numpy(), want[0])
     assert np.array_equal(snaps[1].cpu().numpy(), sc.render(rtamd.RenderOptions(max_depth=0), 96, 64, want_f32=False)[1])
+
+
+def test_one_context_over_several_devices(rtamd, oracle):
+    """rt_context_create with more than one device: every device traces its interleaved tiles, peer
+    copies bring them to the first device, one de-interleave gives the caller the whole image.  On
+    the one GPU of this box the "devices" are the same ordinal several times, which runs every step
+    (scene copies, per-rank frames, peer copies, gather buffer, de-interleave) but the link."""
+    import torch
+    text = read_nff("extra-glass")
+    o = oracle.OracleScene(text)
+    for devices in ([0, 0], [0, 0, 0]):
+        ctx = rtamd.Context(devices)
+        assert rtamd.lib().rt_context_device_count(ctx._h) == len(devices)
+        sc = rtamd.Scene.from_nff(ctx, text)
+        for (w, h, depth) in ((203, 117, 5), (64, 64, 10), (203, 117, 5)):
+            of, ou, octr, _ = o.render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, threads=8)
+            gf, gu, st = sc.render(rtamd.RenderOptions(max_depth=depth), w, h)
+            assert np.array_equal(bits(gf), bits(of)) and np.array_equal(gu, ou), (devices, w, h)
+            for k in RAY_KEYS:
+                assert st.as_dict()[k] == octr[k], k
+        # device outputs on the caller's stream
+        out = torch.zeros((117, 203, 3), dtype=torch.uint8, device="cuda")
+        sc.render_device(rtamd.RenderOptions(max_depth=5), None, out.data_ptr(), torch.cuda.current_stream().cuda_stream, 203, 117)
+        assert np.array_equal(out.cpu().numpy(), o.render(203, 117, max_depth=5, want_f32=False, pow_mode=oracle.POW_PORTABLE)[1])
+        # what such a context does not serve is refused, not mis-served
+        with pytest.raises(rtamd.RtError) as e:
+            sc.render(rtamd.RenderOptions(tile_rank=0, tile_count=2))
+        assert e.value.code == rtamd.RT_ERR_UNSUPPORTED
+        with pytest.raises(rtamd.RtError):
+            sc.render_device_begin(rtamd.RenderOptions(), None, out.data_ptr(), None, 203, 117)
+    with pytest.raises(rtamd.RtError):
+        rtamd.Context([0, 99])
+
+
+def test_tile_gather_over_rccl_with_one_rank(rtamd, oracle, gpu_ctx):
+    """TileGather -- what bench.py's step() runs on every rank -- with the nccl backend (RCCL) on
+    device tensors, world size 1: the compact tile buffer of the only rank goes through
+    torch.distributed.gather and the de-interleave kernel, frame after frame, begun without
+    waiting as in the benchmark."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        text = read_nff("extra-glass")
+        sc = rtamd.Scene.from_nff(gpu_ctx, text)
+        w, h = 203, 117
+        tg = rtamd.TileGather(w, h, 0, 1, "cuda", gpu_ctx)
+        opt = tg.options(max_depth=6)
+        stream = torch.cuda.current_stream().cuda_stream
+        tickets = []
+        for _ in range(5):
+            if len(tickets) == 2:
+                sc.render_device_end(tickets.pop(0))
+            tickets.append(sc.render_device_begin(opt, None, tg.mine.data_ptr(), stream, w, h))
+            tg.gather(stream)
+        for t in tickets:
+            sc.render_device_end(t)
+        torch.cuda.synchronize()
+        _, ou, _, _ = oracle.OracleScene(text).render(w, h, max_depth=6, pow_mode=oracle.POW_PORTABLE, want_f32=False)
+        assert np.array_equal(tg.image.cpu().numpy(), ou)
+    finally:
+        dist.destroy_process_group()

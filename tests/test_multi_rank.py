@@ -1,10 +1,11 @@
-"""CPU, world_size 2 over gloo: the multi-GPU data path without GPUs.
+"""CPU, world_size 2 and 3 over gloo: the multi-GPU data path without GPUs.
 
 Each rank owns the interleaved 8x8 tiles t % world == rank of the image.  Here the
 "rendered" tile buffers are cut out of one oracle image with the library's own index
-math (rt_tile_slot), gathered to rank 0 with torch.distributed (the same call the GPU
-path makes over RCCL) and de-interleaved with rt_deinterleave_host; the result must be
-the original image bit for bit, and the per-rank ray counts must sum to the whole.
+math (rt_tile_slot) and handed to TileGather -- the very object bench.py's step() calls on
+every rank -- which gathers them to rank 0 with torch.distributed and de-interleaves; the
+result must be the original image bit for bit, and the per-rank pixel counts must sum to the
+whole.  (tests/test_gpu_render.py runs the same object over nccl on the one GPU.)
 """
 import os
 import socket
@@ -35,8 +36,11 @@ def worker(rank, world, port, w, h, img_path, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     img = np.load(img_path)
-    stride = rtamd.tile_pixels_max(w, h, world)
-    mine = np.zeros((stride, 3), np.uint8)
+    tg = rtamd.TileGather(w, h, rank, world, "cpu")
+    assert tg.stride == rtamd.tile_pixels_max(w, h, world)
+    opt = tg.options(max_depth=3)
+    assert (opt.tile_rank, opt.tile_count) == (rank, world)
+    mine = tg.mine.numpy()
     owned = 0
     for y in range(h):
         for x in range(w):
@@ -45,15 +49,12 @@ def worker(rank, world, port, w, h, img_path, out_path):
                 mine[slot] = img[y, x]
                 owned += 1
     assert owned <= rtamd.tile_pixels(w, h, rank, world)
-    t = torch.from_numpy(mine)
-    bufs = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
-    dist.gather(t, bufs, dst=0)
+    for _ in range(2):  # (frame after frame into the same buffers)
+        tg.gather()
     cnt = torch.tensor([owned], dtype=torch.int64)
     dist.all_reduce(cnt)
     if rank == 0:
-        gathered = torch.stack(bufs).numpy()
-        full = rtamd.deinterleave_host(w, h, world, gathered)
-        np.save(out_path, full)
+        np.save(out_path, tg.image.numpy())
         assert int(cnt.item()) == w * h
     dist.barrier()
     dist.destroy_process_group()
