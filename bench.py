@@ -77,16 +77,18 @@ PEAK_PLAIN_TOPS = 78.6
 
 
 def measured_traffic(args):
-    """HBM-side bytes of one frame from the committed PMC profile of this exact workload
-    (tools/profile.sh + tools/pmc_sum.py; counters need rocprofv3, so they are not collected
-    inside this run), or None for any other workload."""
+    """HBM-side bytes from the committed PMC profile of this exact workload (tools/profile.sh +
+    tools/pmc_sum.py: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over a serial-
+    schedule run, FETCH_SIZE doubled as gfx950 needs; counters need rocprofv3, so they are not
+    collected inside this run): (the file's contents, its path relative to the repository), or
+    (None, None) for any other workload."""
     if (args.scene, args.size, args.width, args.height, args.depth, args.fp) != ("balls", 4, 3840, 2160, 8, "exact"):
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_balls4k_depth8_exact_final.json")))
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_balls4k_depth8_exact_serial.json")))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
-        return json.load(f).get("hbm_bytes_per_frame")
+        return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
 def parse_args():
@@ -104,6 +106,11 @@ def parse_args():
     ap.add_argument("--lights", type=int, default=0, help="mount only: number of point lights")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--in-flight", default="auto", help="frames kept queued: a number, or auto = measured (2 or 4) before the warmup")
+    ap.add_argument("--serial", action="store_true",
+                    help="timed frames one at a time on the serial schedule (one stream, one shadow launch): what the "
+                         "per-kernel profiles under profiles/ are taken with")
+    ap.add_argument("--force-tiles", action="store_true",
+                    help="one rank, but through the tile buffer, the RCCL gather and the de-interleave of a multi-GPU run")
     return ap.parse_args()
 
 
@@ -115,8 +122,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    tiled = world > 1 or args.force_tiles
+    if tiled:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     rtamd = importlib.import_module("rust-raytracer_amd")
     spd = importlib.import_module("rust-raytracer_amd.spd")
@@ -134,10 +144,11 @@ def main():
     setup_s = time.perf_counter() - t0
     ti = scene.tree_info
     fp_mode = rtamd.FP_EXACT if args.fp == "exact" else rtamd.FP_FAST
-    opt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world)
+    opt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world, compact_tiles=tiled,
+                              serial_schedule=args.serial)
 
     stream = torch.cuda.current_stream().cuda_stream
-    if world > 1:  # every rank's compact tile buffer, gathered to rank 0 and de-interleaved there
+    if tiled:  # every rank's compact tile buffer, gathered to rank 0 and de-interleaved there
         tg = rtamd.TileGather(W, H, rank, world, "cuda", ctx)
         image, mine = tg.image, tg.mine
     else:
@@ -152,9 +163,9 @@ def main():
     def step():
         if len(pending) >= in_flight[0]:
             stats.append(scene.render_device_end(pending.pop(0)))
-        target = image if world == 1 else mine
+        target = mine if tiled else image
         pending.append(scene.render_device_begin(opt, None, target.data_ptr(), stream))
-        if world > 1:
+        if tiled:
             tg.gather(stream)
 
     def drain():
@@ -169,7 +180,9 @@ def main():
 
     # How many frames to keep queued: measured here, outside the timed region (long frames do best
     # with two, frames of a few milliseconds with four); every rank takes the same decision.
-    if args.in_flight == "auto":
+    if args.serial:
+        in_flight[0] = 1
+    elif args.in_flight == "auto":
         cand = [c for c in (2, 4) if c <= ctx.frames_in_flight]
         took = []
         for c in cand:
@@ -218,35 +231,87 @@ def main():
     elapsed_max = float(mx[0])
     rays_frame = float(sm[1])
 
-    # ---- work counters for the roofline: one instrumented frame, outside the timed region
-    wopt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world,
-                               collect_work=True)
+    # ---- after the timed region: what one frame at a time costs, the kernels' own times, and the
+    # work counters (one instrumented frame each), all on this rank's share
+    target_ptr = (mine if tiled else image).data_ptr()
+
+    def base_opt(**kw):
+        if args.serial:  # (a profile of this run then sees the timed kernels in serial-schedule launches only)
+            kw["serial_schedule"] = True
+        return rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world,
+                                   compact_tiles=tiled, **kw)
+
+    # one frame at a time through rt_render_device: the library's default two-stream schedule, nothing
+    # else queued (what a render()-shaped caller that keeps its image on the device sees)
+    single = []
+    for k in range(6):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        scene.render_device(base_opt(), None, target_ptr, stream)
+        torch.cuda.synchronize()
+        single.append((time.perf_counter() - t1) * 1e3)
+    single_ms = float(np.median(single[1:]))
+    # the kernels' own times: serial schedule (one stream, all shadow rays in one launch), HIP events
+    # between the launches on the stream they run on
+    serial = [scene.render_device(base_opt(serial_schedule=True), None, target_ptr, stream) for _ in range(6)][1:]
+    kernel_ms = {k: float(np.mean([getattr(x, k) for x in serial]))
+                 for k in ("ms_intersect0", "ms_intersect_deep", "ms_shadow", "ms_light", "ms_resolve", "ms_frame")}
+
     def counted(o):
-        w = scene.render_device(o, None, (image if world == 1 else mine).data_ptr(), stream).as_dict()  # (one at a time)
-        vec = torch.tensor([float(w[k]) for k in sorted(w)], dtype=torch.float64, device="cuda")
+        st_w = scene.render_device(o, None, target_ptr, stream)  # (one at a time)
+        w, ws = st_w.as_dict(), st_w.shadow_work()
+        keys = sorted(w)
+        vec = torch.tensor([float(w[k]) for k in keys] + [float(ws[k]) for k in sorted(ws)], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        return dict(zip(sorted(w), (float(x) for x in vec.cpu().numpy())))
+        vals = [float(x) for x in vec.cpu().numpy()]
+        return dict(zip(keys, vals[: len(keys)])), dict(zip(sorted(ws), vals[len(keys):]))
 
-    work = counted(wopt)  # what the timed kernels execute
-    wopt.exhaustive_leaves = True
-    ref_work = counted(wopt)  # what the reference's leaf walk executes for the same frame
+    work, work_shadow = counted(base_opt(collect_work=True))  # what the timed kernels execute
+    ref_work, _ = counted(base_opt(collect_work=True, exhaustive_leaves=True))  # the reference's own leaf walk, same frame
+
+    # the rt_render()-shaped call: host buffer out, D2H copy included (rank 0 of a one-GPU run only)
+    host_ms = None
+    if world == 1 and not tiled:
+        took = []
+        for k in range(3):
+            t1 = time.perf_counter()
+            scene.render(base_opt(), W, H, want_f32=False)
+            took.append((time.perf_counter() - t1) * 1e3)
+        host_ms = float(np.median(took[1:]))
 
     if rank != 0:
-        if world > 1:
+        if tiled:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    traffic = measured_traffic(args)
-    flops = sum(work[k] * (c - FLOP_SAVED.get(k, 0)) for k, c in FLOP.items())
+    traffic, traffic_file = measured_traffic(args)
+    def flops_of(w):
+        return sum(w.get(k, 0.0) * (c - FLOP_SAVED.get(k, 0)) for k, c in FLOP.items())
+    flops = flops_of(work)
     nodes_frame = work["rays_primary"] + work["rays_reflect"] + work["rays_refract"]
     abytes = sum(work[k] * c for k, c in BYTES.items()) + nodes_frame * RAY_STATE_BYTES + W * H * FRAMEBUFFER_BYTES
     ms_per_step = elapsed_max / args.steps * 1e3
-    # GPU time one frame takes up: with several frames in flight their launches overlap, so a frame's
-    # own first-to-last span (frame_ms.device_frame, its latency) counts shared time twice
-    trace_s = min(float(mx[6]), ms_per_step) * 1e-3
     value = rays_frame * args.steps / elapsed_max / 1e6
+    # The dominant kernel: k_shadow (the frame's shadow rays, three quarters of all rays on balls).  Its
+    # algorithmic work = its own counters x the per-event FLOPs, its bytes = one 32-byte ray read and one
+    # 4-byte flag written per shadow ray plus what its tests request (cache-served); its duration = its
+    # launch in the serial-schedule frames above.
+    sh_flops = flops_of(work_shadow)
+    sh_rays = work["rays_shadow"]
+    sh_bytes = sh_rays * (32 + 4) + sum(work_shadow.get(k, 0.0) * c for k, c in BYTES.items())
+    sh_s = kernel_ms["ms_shadow"] * 1e-3 if kernel_ms["ms_shadow"] > 0 else float("nan")
+    sh_traffic = traffic.get("k_shadow", {}).get("hbm_bytes_per_launch") if traffic else None
+    src_commit = None
+    if traffic_file:
+        try:
+            import subprocess
+            src_commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", traffic_file], capture_output=True,
+                                        text=True, timeout=10).stdout.strip() or None
+        except Exception:
+            src_commit = None
+    frame_s = kernel_ms["ms_frame"] * 1e-3
 
     out = {
         "metric": "Mrays/s (all ray types), SPD balls @3840x2160",
@@ -264,45 +329,63 @@ def main():
         "config": {
             "workload": f"SPD-style {args.scene} size {args.size} ({ti.n_leaf_refs} leaf refs in {ti.n_nodes} nodes, "
                         f"depth {ti.max_depth}, largest leaf {ti.max_leaf}), {W}x{H}, max_depth {args.depth}, "
-                        f"Phong, fp_mode {args.fp}",
-            "parallelism": f"interleaved 8x8 tiles over {world} GPU(s), RCCL gather to rank 0" if world > 1
-                           else "single GPU, whole image",
+                        f"Phong, fp_mode {args.fp}, {in_flight[0]} frame(s) in flight"
+                        + (", serial schedule" if args.serial else ""),
+            "parallelism": (f"interleaved 8x8 tiles over {world} GPU(s), RCCL gather to rank 0" if tiled
+                            else "single GPU, whole image"),
+            "frames_in_flight": in_flight[0],
             "rays_per_frame": {"primary": int(sm[2]), "shadow": int(sm[3]), "reflect": int(sm[4]),
                                "refract": int(sm[5]), "total": int(rays_frame)},
             "setup_s": round(setup_s, 3), "tree_build_ms": round(ti.build_ms, 1),
         },
-        "frame_ms": {"trace_kernels": round(float(mx[6]), 4), "resolve_kernels": round(float(mx[7]), 4),
-                     "device_frame": round(float(mx[8]), 4), "step_wall": round(ms_per_step, 4),
-                     "frames_in_flight": in_flight[0]},
+        # step_wall: the timed region / steps (frames overlap when several are in flight); single_frame: one
+        # frame at a time, image left in HBM (median wall time of rt_render_device); single_frame_host:
+        # rt_render into a host buffer, D2H copy of the u8 image included; device_frame: a frame's own
+        # first-to-last-kernel span inside the timed region (its latency under the overlap)
+        "frame_ms": {"step_wall": round(ms_per_step, 4), "single_frame": round(single_ms, 4),
+                     "single_frame_host": round(host_ms, 4) if host_ms is not None else None,
+                     "device_frame": round(float(mx[8]), 4), "frames_in_flight": in_flight[0],
+                     "kernels_serial": {k: round(v, 4) for k, v in kernel_ms.items()}},
         "roofline": {
+            # neither "hbm" nor "mfma" binds this path (no dense contraction; scene data is cache resident):
+            # vector issue with few waves ready per SIMD does.  The HBM view is alongside.
             "bound": "valu",
-            "kernel": "trace phase of one frame: k_intersect of every bounce level, k_shadow, k_light",
-            "achieved": round(flops / trace_s / 1e12, 4),
+            "kernel": "k_shadow<6, NoCounters> (lean build of the shadow kernel; <2, NoCounters> on scenes with cones or polygon records)",
+            "achieved": round(sh_flops / sh_s / 1e12, 4),
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": round(flops / trace_s / 1e12 / PEAK_F32_TFLOPS, 5),
-            "traffic": traffic,
-            "executed_flops_per_frame": flops,
-            # bytes the counted tests request; the scene is cache resident, so most never reach HBM
-            "requested_bytes_per_frame": abytes,
-            "hbm_achieved_GBs": round(traffic / trace_s / 1e9, 3) if traffic else None,
-            "hbm_peak_GBs": PEAK_HBM_GBS,
-            "hbm_frac": round(traffic / trace_s / 1e9 / PEAK_HBM_GBS, 6) if traffic else None,
-            "plain_op_ceiling": {"achieved": round(flops / trace_s / 1e12, 4), "peak": PEAK_PLAIN_TOPS, "unit": "Tops/s",
-                                 "frac": round(flops / trace_s / 1e12 / PEAK_PLAIN_TOPS, 5)},
-            "walk_lane_use": round((work["bound_tests"] + work["sphere_tests"]) / work["lane_slots"], 4)
-                             if work.get("lane_slots") else None,
-            "reference_equivalent_TFLOPs": round(sum(ref_work[k] * c for k, c in FLOP.items()) / trace_s / 1e12, 2),
-            "work": {k: int(v) for k, v in work.items()},
-            "reference_work": {k: int(ref_work[k]) for k in ("node_visits", "sphere_tests", "cone_tests", "poly_tests")},
-            "reference_flops_per_frame": sum(ref_work[k] * c for k, c in FLOP.items()),
+            "frac": round(sh_flops / sh_s / 1e12 / PEAK_F32_TFLOPS, 5),
+            "traffic": sh_traffic,
+            "traffic_source": {"file": traffic_file, "commit": src_commit} if traffic_file else None,
+            "launch_ms": round(kernel_ms["ms_shadow"], 4),
+            "launch_measured": "mean of 5 serial-schedule frames in this run, HIP events around the launch on its stream",
+            "flops_per_launch": sh_flops,
+            "units_per_launch": {"shadow_rays": int(sh_rays)},
+            "flops_per_unit": round(sh_flops / sh_rays, 2) if sh_rays else None,
+            "algorithmic_bytes_per_launch": sh_bytes,
+            "plain_op_ceiling": {"achieved": round(sh_flops / sh_s / 1e12, 4), "peak": PEAK_PLAIN_TOPS, "unit": "Tops/s",
+                                 "frac": round(sh_flops / sh_s / 1e12 / PEAK_PLAIN_TOPS, 5)},
+            "hbm": {"achieved_GBs": round(sh_traffic / sh_s / 1e9, 2) if sh_traffic else None, "peak_GBs": PEAK_HBM_GBS,
+                    "frac": round(sh_traffic / sh_s / 1e9 / PEAK_HBM_GBS, 5) if sh_traffic else None},
+            "walk_lane_use": round((work_shadow["bound_tests"] + work_shadow["sphere_tests"]) / work_shadow["lane_slots"], 4)
+                             if work_shadow.get("lane_slots") else None,
+            "work": {k: int(v) for k, v in work_shadow.items() if v},
+            # the whole frame, serial schedule (sum of its kernels' own times)
+            "frame": {"executed_flops": flops, "ms": round(kernel_ms["ms_frame"], 4),
+                      "achieved": round(flops / frame_s / 1e12, 4), "frac": round(flops / frame_s / 1e12 / PEAK_F32_TFLOPS, 5),
+                      "plain_op_frac": round(flops / frame_s / 1e12 / PEAK_PLAIN_TOPS, 5),
+                      "requested_bytes": abytes,
+                      "hbm_bytes": traffic.get("hbm_bytes_per_frame") if traffic else None,
+                      "reference_equivalent_TFLOPs": round(sum(ref_work[k] * c for k, c in FLOP.items()) / frame_s / 1e12, 2),
+                      "work": {k: int(v) for k, v in work.items()},
+                      "reference_work": {k: int(ref_work[k]) for k in ("node_visits", "sphere_tests", "cone_tests", "poly_tests")}},
         },
     }
 
     if not args.no_cpu and world == 1:  # (the CPU baseline is a single-GPU-run figure: rank 0, N = 1)
         out["cpu_baseline"], out["parity_sample"] = cpu_baseline(args, text, image)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if tiled:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -136,6 +136,9 @@ typedef struct rt_options {
                                 sphere proves that the reference's test rejects them -- same image */
     uint32_t compact_tiles;  /* nonzero: write the compact tile buffer (rt_tile_pixels slots) even when
                                 tile_count is 0 or 1, so that one rank runs the code path of many */
+    uint32_t serial_schedule; /* nonzero: every kernel of the frame on one stream, all shadow rays in one
+                                launch after the last bounce level, and the per-kernel times of rt_stats
+                                filled (HIP events between the launches).  For measurement: slower */
 } rt_options;
 
 typedef struct rt_stats {
@@ -156,6 +159,13 @@ typedef struct rt_stats {
     double ms_resolve;    /* sum over resolve kernel launches */
     double ms_frame;      /* first launch -> framebuffer complete on device */
     double ms_d2h;        /* copy to the caller's host buffers (rt_render only) */
+    /* the shadow kernel's share of `work` (k_shadow: closest hit per shadow ray, src/scene.rs:108-117) */
+    uint64_t work_shadow[16];
+    /* with rt_options.serial_schedule: each kernel's own time, nothing else running beside it */
+    double ms_intersect0;     /* closest hits of the camera rays + the rays they spawn (k_intersect, level 0) */
+    double ms_intersect_deep; /* the same for all deeper bounce levels */
+    double ms_shadow;         /* k_shadow, all levels in one launch */
+    double ms_light;          /* k_light */
 } rt_stats;
 
 typedef struct rt_tree_info {

@@ -113,14 +113,16 @@ class rt_scene_desc(C.Structure):
 class rt_options(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("min_contribution", C.c_float), ("fp_mode", C.c_uint32),
                 ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32), ("collect_work", C.c_uint32),
-                ("exhaustive_leaves", C.c_uint32), ("compact_tiles", C.c_uint32)]
+                ("exhaustive_leaves", C.c_uint32), ("compact_tiles", C.c_uint32), ("serial_schedule", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
                 ("rays_refract", C.c_uint64), ("work", C.c_uint64 * 16), ("ray_nodes", C.c_uint64),
                 ("levels", C.c_uint32), ("retries", C.c_uint32), ("ms_trace", C.c_double), ("ms_resolve", C.c_double),
-                ("ms_frame", C.c_double), ("ms_d2h", C.c_double)]
+                ("ms_frame", C.c_double), ("ms_d2h", C.c_double), ("work_shadow", C.c_uint64 * 16),
+                ("ms_intersect0", C.c_double), ("ms_intersect_deep", C.c_double), ("ms_shadow", C.c_double),
+                ("ms_light", C.c_double)]
 
     @property
     def rays_total(self):
@@ -131,6 +133,10 @@ class rt_stats(C.Structure):
              "rays_refract": self.rays_refract}
         d.update({n: int(self.work[i]) for i, n in enumerate(WORK_NAMES + CULL_NAMES)})
         return d
+
+    def shadow_work(self):
+        """The shadow kernel's share of the work counters."""
+        return {n: int(self.work_shadow[i]) for i, n in enumerate(WORK_NAMES + CULL_NAMES)}
 
 
 class rt_tree_info(C.Structure):
@@ -362,10 +368,12 @@ class RenderOptions:
     collect_work: bool = False
     exhaustive_leaves: bool = False  # True: no bounding-sphere culling inside big leaves (same image, slower)
     compact_tiles: bool = False      # True: compact tile buffer as output even for a single rank
+    serial_schedule: bool = False    # True: one stream, one shadow launch, per-kernel times in rt_stats (measurement)
 
     def c(self):
         return rt_options(self.max_depth, self.min_contribution, self.fp_mode, self.tile_rank, self.tile_count,
-                          int(self.collect_work), int(self.exhaustive_leaves), int(self.compact_tiles))
+                          int(self.collect_work), int(self.exhaustive_leaves), int(self.compact_tiles),
+                          int(self.serial_schedule))
 
 
 class Scene:

@@ -94,6 +94,8 @@ struct FrameSlot {
     hipEvent_t ev_shadow = nullptr;                  // all shadow launches done
     hipEvent_t ev_caller = nullptr;                  // what the caller's stream held when the frame began
     hipEvent_t ev_done = nullptr;                    // frame finished and its counters copied to the host
+    hipEvent_t ev_t[RT_MAX_LEVELS + 2] = {};         // serial schedule: after each intersect level, the shadow launch, the light launch
+    uint32_t timed_levels = 0;                       // ev_t[0 .. timed_levels) are intersect levels of this frame; 0 = not a timed frame
     uint32_t* h_levels = nullptr;                    // pinned copies of `levels` and `counters`, filled by the frame
     unsigned long long* h_counters = nullptr;        // itself (a blocking copy would wait for the other frame too)
     // the frame in flight
@@ -162,6 +164,7 @@ struct rt_scene {
 namespace {
 
 constexpr uint32_t LV_SHADOW_COUNT = 2 * RT_MAX_LEVELS, LV_OVERFLOW = 3 * RT_MAX_LEVELS, LV_WORDS = 3 * RT_MAX_LEVELS + 1;
+constexpr uint32_t N_COUNTERS = 40;  // see FrameArgs::counters
 constexpr uint32_t SHADOW_GROUP_FROM = 4;  // levels from here on are too small to fill the GPU: one shadow launch for all
 
 int fail(rt_context* ctx, int code, const std::string& msg) {
@@ -266,8 +269,9 @@ int setup_slot(rt_context* ctx, FrameSlot& f) {
     RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_shadow, hipEventDisableTiming));
     RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_caller, hipEventDisableTiming));
     RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
+    for (auto& e : f.ev_t) RT_HIP(ctx, hipEventCreate(&e));
     RT_HIP(ctx, hipHostMalloc((void**)&f.h_levels, LV_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    RT_HIP(ctx, hipHostMalloc((void**)&f.h_counters, 20 * sizeof(unsigned long long), hipHostMallocDefault));
+    RT_HIP(ctx, hipHostMalloc((void**)&f.h_counters, N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault));
     return RT_OK;
 }
 
@@ -280,6 +284,8 @@ void teardown_slot(FrameSlot& f) {
     if (f.ev_shadow) (void)hipEventDestroy(f.ev_shadow);
     if (f.ev_caller) (void)hipEventDestroy(f.ev_caller);
     if (f.ev_done) (void)hipEventDestroy(f.ev_done);
+    for (auto& e : f.ev_t)
+        if (e) (void)hipEventDestroy(e);
     if (f.h_levels) (void)hipHostFree(f.h_levels);
     if (f.h_counters) (void)hipHostFree(f.h_counters);
     if (f.shadow_stream) (void)hipStreamDestroy(f.shadow_stream);
@@ -312,7 +318,7 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         int rc = setup_slot(ctx, f);
         if (rc != RT_OK) return rc;
         RT_HIP(ctx, f.levels.alloc(LV_WORDS));
-        RT_HIP(ctx, f.counters.alloc(20));
+        RT_HIP(ctx, f.counters.alloc(N_COUNTERS));
         f.ws.levels = f.levels.p;
         f.ws.counters = f.counters.p;
     }
@@ -750,13 +756,16 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // gives a process four hardware queues, so that is the schedule for up to two frames in flight.
     // A caller that keeps three or four queued gets one stream per frame instead: the frames fill
     // each other's gaps, and more streams than queues would only take turns on them.
-    hipStream_t st = f.main_stream, st2 = f.one_stream ? f.main_stream : f.shadow_stream;
+    const bool serial = opt->serial_schedule != 0;
+    const bool one_stream = f.one_stream || serial;
+    hipStream_t st = f.main_stream, st2 = one_stream ? f.main_stream : f.shadow_stream;
+    f.timed_levels = 0;
     // What the caller's stream holds now comes before this attempt's writes to the caller's buffers.
     // (A re-run from rt_render_device_end records it afresh: frames begun in the meantime into the
     // same buffers, and whatever consumes them, are on that stream by then.)
     RT_HIP(ctx, hipEventRecord(f.ev_caller, f.caller));
     RT_HIP(ctx, hipMemsetAsync(ws.levels, 0, LV_WORDS * sizeof(uint32_t), st));
-    RT_HIP(ctx, hipMemsetAsync(ws.counters, 0, 20 * sizeof(unsigned long long), st));
+    RT_HIP(ctx, hipMemsetAsync(ws.counters, 0, N_COUNTERS * sizeof(unsigned long long), st));
     RT_HIP(ctx, hipEventRecord(f.ev[0], st));
 
     const uint32_t grid0 = std::max<uint32_t>(1, (n_slots + RT_BLOCK - 1) / RT_BLOCK);
@@ -786,15 +795,20 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     for (uint32_t level = 0; level <= last_level; ++level) {
         const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
+        if (serial) {
+            RT_HIP(ctx, hipEventRecord(f.ev_t[level], st));
+            f.timed_levels = level + 1;
+        }
         if (n_lights) {  // this level's shadow rays and lighting: beside the next levels, on the second stream
             RT_HIP(ctx, hipEventRecord(f.ev_level[level], st));
-            if (f.one_stream) {
+            if (one_stream) {
                 // one stream: the chain of intersections first, without a shadow launch between two
                 // levels, then every level's shadow rays in one launch (the other frames in flight
                 // fill the GPU under the small launches of the deep levels)
                 if (level == last_level) {
                     rc = shadow_rays(0, level);
                     if (rc != RT_OK) return rc;
+                    if (serial) RT_HIP(ctx, hipEventRecord(f.ev_t[f.timed_levels], st));
                 }
             } else if (level < SHADOW_GROUP_FROM || level == last_level) {
                 const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
@@ -812,6 +826,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
             RT_HIP(ctx, fast ? rt_fast::launch_light(A, 0, last_level, work, gl, st2)
                              : rt_exact::launch_light(A, 0, last_level, work, gl, st2));
         }
+        if (serial) RT_HIP(ctx, hipEventRecord(f.ev_t[f.timed_levels + 1], st));
         RT_HIP(ctx, hipEventRecord(f.ev_shadow, st2));
         RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_shadow, 0));
     }
@@ -824,7 +839,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     RT_HIP(ctx, hipEventRecord(f.ev[2], st));
     RT_HIP(ctx, hipStreamWaitEvent(f.caller, f.ev[2], 0));
     RT_HIP(ctx, hipMemcpyAsync(f.h_levels, ws.levels, LV_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipMemcpyAsync(f.h_counters, ws.counters, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(f.h_counters, ws.counters, N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipEventRecord(f.ev_done, st));
     return RT_OK;
 }
@@ -866,14 +881,17 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
         // what the next frames' pools should hold, on every slot: this frame's need and a quarter more
         ctx->want_pool = std::max<size_t>(ctx->want_pool, (size_t)need + (need >> 2));
         ctx->want_shadow1 = std::max<size_t>(ctx->want_shadow1, (size_t)sneed + (sneed >> 2));
-        unsigned long long c[20];
+        unsigned long long c[N_COUNTERS];
         memcpy(c, f.h_counters, sizeof(c));
         stats.rays_primary = p.n_primary;
         stats.rays_shadow = 0;
         for (uint32_t l = 0; l <= opt->max_depth; ++l) stats.rays_shadow += (uint64_t)lv[LV_SHADOW_COUNT + l] * p.n_lights;
         stats.rays_reflect = c[2];
         stats.rays_refract = c[3];
-        for (int k = 0; k < 16; ++k) stats.work[k] = c[4 + k];
+        for (int k = 0; k < 16; ++k) {
+            stats.work[k] = c[4 + k] + c[24 + k];
+            stats.work_shadow[k] = c[24 + k];
+        }
         ctx->hint_scene = f.scene;
         ctx->hint_slots = p.n_slots;
         ctx->hint_depth = opt->max_depth;
@@ -894,6 +912,21 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
         stats.ms_trace = ms01;
         stats.ms_resolve = ms12;
         stats.ms_frame = ms02;
+        if (f.timed_levels != 0) {  // serial schedule: the kernels' own times
+            float ms = 0;
+            RT_HIP(ctx, hipEventElapsedTime(&ms, f.ev[0], f.ev_t[0]));
+            stats.ms_intersect0 = ms;
+            if (f.timed_levels > 1) {
+                RT_HIP(ctx, hipEventElapsedTime(&ms, f.ev_t[0], f.ev_t[f.timed_levels - 1]));
+                stats.ms_intersect_deep = ms;
+            }
+            if (p.n_lights) {
+                RT_HIP(ctx, hipEventElapsedTime(&ms, f.ev_t[f.timed_levels - 1], f.ev_t[f.timed_levels]));
+                stats.ms_shadow = ms;
+                RT_HIP(ctx, hipEventElapsedTime(&ms, f.ev_t[f.timed_levels], f.ev_t[f.timed_levels + 1]));
+                stats.ms_light = ms;
+            }
+        }
         break;
     }
     if (stats_out) *stats_out = stats;
@@ -1027,7 +1060,7 @@ extern "C" int rt_render_device_static(rt_context* ctx, const rt_scene* scene, c
     // same number of entries (a frame has at most one lit hit per ray-tree node).  That number is a
     // multiple of 64, which keeps every array on a 256-byte boundary.
     constexpr size_t HEAD = 4096;
-    static_assert(LV_WORDS * sizeof(uint32_t) <= 2048 && 20 * sizeof(unsigned long long) <= 2048, "counters fit the head");
+    static_assert(LV_WORDS * sizeof(uint32_t) <= 2048 && N_COUNTERS * sizeof(unsigned long long) <= 2048, "counters fit the head");
     const size_t per_entry = NODE_BYTES + SHADOW_BYTES * p.lights1;
     const size_t cap = ((RT_STATIC_WORKSPACE_BYTES - HEAD) / per_entry) & ~(size_t)63;
     if (cap < p.n_slots || cap < 64)

@@ -45,12 +45,13 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-template <class Ctr>
+// counters[4 .. 20): work of k_intersect and k_light; counters[24 .. 40): work of k_shadow
+template <int BASE = 4, class Ctr>
 RT_DEV void flush_work(const FrameArgs& A, Ctr& ctr) {
     if constexpr (Ctr::kEnabled) {
         for (int k = 0; k < 16; ++k) {
             const uint32_t s = wave_sum(ctr.c[k]);
-            if (lane_id() == 0 && s) atomicAdd(&A.counters[4 + k], (unsigned long long)s);
+            if (lane_id() == 0 && s) atomicAdd(&A.counters[BASE + k], (unsigned long long)s);
         }
     }
 }
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A
             blocked = blocker.dist <= so.w;
         A.sray_blocked[i] = blocked ? 1u : 0u;
     }
-    flush_work(A, ctr);
+    flush_work<24>(A, ctr);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -82,7 +82,7 @@ struct FrameArgs {
     uint32_t* shadow_count; // [RT_MAX_LEVELS] lit hits of each level (each takes one slot in every queue);
                             // a level's slots follow those of the levels before it
     uint32_t* overflow;
-    unsigned long long* counters;  // [17]: primary, shadow, reflect, refract, then the 13 work counters
+    unsigned long long* counters;  // [40]: -, -, reflect, refract, 16 work counters of k_intersect / k_light, 4 unused, 16 of k_shadow
     // outputs (either may be null)
     float* out_f32;
     uint8_t* out_u8;

@@ -47,6 +47,24 @@ def main():
                "hbm_bytes_per_frame": int(2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]),
                "method": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, per-kernel sums of the timed "
                          "frames' kernels, FETCH_SIZE x 2 (gfx950), / frames"}
+        # per launch, for the kernels of the timed frames (meaningful for a run on the serial schedule,
+        # where a frame launches each of them a fixed number of times)
+        names = {"k_shadow": "k_shadow<", "k_intersect0": "k_intersect<true", "k_intersect_deep": "k_intersect<false",
+                 "k_light": "k_light<", "k_resolve0": "k_resolve<true", "k_resolve_deep": "k_resolve<false"}
+        for label, needle in names.items():
+            f_sum = w_sum = 0.0
+            n = 0
+            for (kernel, counter), v in sums.items():
+                if needle not in kernel or "WorkCounters" in kernel:
+                    continue
+                if counter == "FETCH_SIZE":
+                    f_sum += v * 1024.0
+                    n = max(n, len(disp[(kernel, counter)]))
+                elif counter == "WRITE_SIZE":
+                    w_sum += v * 1024.0
+            if n:
+                out[label] = {"launches": n, "fetch_bytes_per_launch": int(2 * f_sum / n), "write_bytes_per_launch": int(w_sum / n),
+                              "hbm_bytes_per_launch": int((2 * f_sum + w_sum) / n)}
         with open(sys.argv[2], "w") as f:
             json.dump(out, f, indent=1)
             f.write("\n")
