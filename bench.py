@@ -109,6 +109,7 @@ def parse_args():
     ap.add_argument("--serial", action="store_true",
                     help="timed frames one at a time on the serial schedule (one stream, one shadow launch): what the "
                          "per-kernel profiles under profiles/ are taken with")
+    ap.add_argument("--shadow-mode", type=int, default=0, help="rt_options.shadow_mode: 0 closest hit (reference), 1 exact stop, 2 any hit (not parity)")
     ap.add_argument("--force-tiles", action="store_true",
                     help="one rank, but through the tile buffer, the RCCL gather and the de-interleave of a multi-GPU run")
     return ap.parse_args()
@@ -145,7 +146,7 @@ def main():
     ti = scene.tree_info
     fp_mode = rtamd.FP_EXACT if args.fp == "exact" else rtamd.FP_FAST
     opt = rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world, compact_tiles=tiled,
-                              serial_schedule=args.serial)
+                              serial_schedule=args.serial, shadow_mode=args.shadow_mode)
 
     stream = torch.cuda.current_stream().cuda_stream
     if tiled:  # every rank's compact tile buffer, gathered to rank 0 and de-interleaved there
@@ -239,7 +240,7 @@ def main():
         if args.serial:  # (a profile of this run then sees the timed kernels in serial-schedule launches only)
             kw["serial_schedule"] = True
         return rtamd.RenderOptions(max_depth=args.depth, fp_mode=fp_mode, tile_rank=rank, tile_count=world,
-                                   compact_tiles=tiled, **kw)
+                                   compact_tiles=tiled, shadow_mode=args.shadow_mode, **kw)
 
     # one frame at a time through rt_render_device: the library's default two-stream schedule, nothing
     # else queued (what a render()-shaped caller that keeps its image on the device sees)
@@ -330,7 +331,8 @@ def main():
             "workload": f"SPD-style {args.scene} size {args.size} ({ti.n_leaf_refs} leaf refs in {ti.n_nodes} nodes, "
                         f"depth {ti.max_depth}, largest leaf {ti.max_leaf}), {W}x{H}, max_depth {args.depth}, "
                         f"Phong, fp_mode {args.fp}, {in_flight[0]} frame(s) in flight"
-                        + (", serial schedule" if args.serial else ""),
+                        + (", serial schedule" if args.serial else "")
+                        + (f", shadow_mode {args.shadow_mode}" if args.shadow_mode else ""),
             "parallelism": (f"interleaved 8x8 tiles over {world} GPU(s), RCCL gather to rank 0" if tiled
                             else "single GPU, whole image"),
             "frames_in_flight": in_flight[0],

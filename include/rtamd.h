@@ -122,6 +122,19 @@ enum {
     RT_FP_FAST = 1   /* FMA contraction, reciprocal slab test, hardware pow */
 };
 
+/* How a shadow ray decides "blocked" (reference src/scene.rs:108-117: a full closest-hit query,
+ * blocked iff the hit is at most as far as the light). */
+enum {
+    RT_SHADOW_CLOSEST = 0,    /* the reference's walk to its end (default) */
+    RT_SHADOW_EXACT_STOP = 1, /* stops as soon as "blocked" is certain -- a hit before the light that no
+                                 pending node of the walk could replace: same flag, same image.  Measured
+                                 no faster on MI355X (a wave lasts as long as its slowest ray) */
+    RT_SHADOW_ANY_HIT = 2     /* "fast shadows": stops at any hit before the light.  NOT the parity mode: where
+                                 the reference's walk would drop that hit for its far child's result
+                                 (src/space_partition.rs:313-325) this says shadowed and the reference lit;
+                                 never the other way round */
+};
+
 typedef struct rt_options {
     uint32_t max_depth;      /* MAX_DEPTH, reference src/scene.rs:8 (5) */
     float min_contribution;  /* MIN_CONTRIBUTION, reference src/scene.rs:9 (0.003) */
@@ -136,6 +149,7 @@ typedef struct rt_options {
                                 sphere proves that the reference's test rejects them -- same image */
     uint32_t compact_tiles;  /* nonzero: write the compact tile buffer (rt_tile_pixels slots) even when
                                 tile_count is 0 or 1, so that one rank runs the code path of many */
+    uint32_t shadow_mode;    /* RT_SHADOW_* below; ignored (closest hit) with exhaustive_leaves or collect_work */
     uint32_t serial_schedule; /* nonzero: every kernel of the frame on one stream, all shadow rays in one
                                 launch after the last bounce level, and the per-kernel times of rt_stats
                                 filled (HIP events between the launches).  For measurement: slower */

@@ -22,6 +22,7 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_BUILD, RT_ERR_PARSE, RT_ERR_IO, RT_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 FP_EXACT, FP_FAST = 0, 1
+SHADOW_CLOSEST, SHADOW_EXACT_STOP, SHADOW_ANY_HIT = 0, 1, 2
 DEBUG_EXHAUSTIVE = 0x100
 KIND_SPHERE, KIND_CONE, KIND_POLYGON = 0, 1, 2
 NO_PRIM = 0xFFFFFFFF
@@ -113,7 +114,8 @@ class rt_scene_desc(C.Structure):
 class rt_options(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("min_contribution", C.c_float), ("fp_mode", C.c_uint32),
                 ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32), ("collect_work", C.c_uint32),
-                ("exhaustive_leaves", C.c_uint32), ("compact_tiles", C.c_uint32), ("serial_schedule", C.c_uint32)]
+                ("exhaustive_leaves", C.c_uint32), ("compact_tiles", C.c_uint32), ("shadow_mode", C.c_uint32),
+                ("serial_schedule", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
@@ -368,12 +370,13 @@ class RenderOptions:
     collect_work: bool = False
     exhaustive_leaves: bool = False  # True: no bounding-sphere culling inside big leaves (same image, slower)
     compact_tiles: bool = False      # True: compact tile buffer as output even for a single rank
+    shadow_mode: int = 0             # SHADOW_CLOSEST (reference), SHADOW_EXACT_STOP (same image), SHADOW_ANY_HIT (not parity)
     serial_schedule: bool = False    # True: one stream, one shadow launch, per-kernel times in rt_stats (measurement)
 
     def c(self):
         return rt_options(self.max_depth, self.min_contribution, self.fp_mode, self.tile_rank, self.tile_count,
                           int(self.collect_work), int(self.exhaustive_leaves), int(self.compact_tiles),
-                          int(self.serial_schedule))
+                          int(self.shadow_mode), int(self.serial_schedule))
 
 
 class Scene:

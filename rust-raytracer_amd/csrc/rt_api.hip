@@ -443,8 +443,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     // Device nodes + leaf runs.  A leaf's list (src/space_partition.rs:348-385 walks it in order)
     // becomes one run per primitive kind, each in list order with the list position attached.
     static_assert(sizeof(rt_kd_node) == 64, "node layout");
-    std::vector<uint4> nodes(sc->tree.nodes.size() * 4);
-    memcpy(nodes.data(), sc->tree.nodes.data(), sc->tree.nodes.size() * sizeof(rt_kd_node));
+    if (sc->tree.nodes.size() >= (1u << 29)) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^29 partition nodes");
+    std::vector<uint4> nodes(sc->tree.nodes.size() * 4, make_uint4(0, 0, 0, 0));
     std::vector<float4> sph;
     std::vector<uint2> sph_id;
     std::vector<float> bnd;  // 4 floats per record
@@ -458,9 +458,14 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     bool any_poly_walk = false;
     for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
         const rt_kd_node& n = sc->tree.nodes[ni];
-        if (n.axis != 3) {
-            nodes[ni * 4 + 2] = make_uint4(n.under, n.over, 0, 0);
-            nodes[ni * 4 + 3] = make_uint4(0, 0, 0, 0);
+        if (n.axis != 3) {  // {plane, axis, under, over} + the children's boxes
+            const rt_kd_node& u = sc->tree.nodes[n.under];
+            const rt_kd_node& o = sc->tree.nodes[n.over];
+            auto fb = [](float f) { uint32_t b; memcpy(&b, &f, 4); return b; };
+            nodes[ni * 4 + 0] = make_uint4(fb(n.plane), n.axis, n.under, n.over);
+            nodes[ni * 4 + 1] = make_uint4(fb(u.bmin[0]), fb(u.bmin[1]), fb(u.bmin[2]), fb(u.bmax[0]));
+            nodes[ni * 4 + 2] = make_uint4(fb(u.bmax[1]), fb(u.bmax[2]), fb(o.bmin[0]), fb(o.bmin[1]));
+            nodes[ni * 4 + 3] = make_uint4(fb(o.bmin[2]), fb(o.bmax[0]), fb(o.bmax[1]), fb(o.bmax[2]));
             continue;
         }
         const uint32_t s0 = (uint32_t)sph.size(), p0 = (uint32_t)poly_items.size();
@@ -517,9 +522,9 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             sph.push_back(make_float4(e.c[0], e.c[1], e.c[2], e.r * e.r));  // src/sphere.rs:53
             sph_id.push_back(make_uint2(e.prim, e.pos));
         }
-        nodes[ni * 4 + 2] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
-        nodes[ni * 4 + 3] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, pu0);
-        nodes[ni * 4 + 0].w = cu0;  // (a leaf has no plane)
+        nodes[ni * 4 + 0] = make_uint4(cu0, 3u, 0u, 0u);
+        nodes[ni * 4 + 1] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
+        nodes[ni * 4 + 2] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, pu0);
     }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;
@@ -595,6 +600,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     // lean: no cones and next to no polygons (a floor): kernels without the code for either's records
     d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8 && d.stack_depth <= RT_STACK_RING) ? 1u : 0u;
     memcpy(d.bg, sd.background, sizeof(d.bg));
+    memcpy(d.root_min, sc->tree.nodes[0].bmin, sizeof(d.root_min));
+    memcpy(d.root_max, sc->tree.nodes[0].bmax, sizeof(d.root_max));
     if (d.stack_depth > RT_STACK_RING + RT_STACK_DEEP)
         return fail(ctx, RT_ERR_UNSUPPORTED, "space partition deeper than the device traversal stack (64 levels)");
     // a copy of the scene, with this partition, on each further device of the context
@@ -702,6 +709,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.tile_rank = opt->tile_rank;
     A.tile_count = tile_count;
     A.compact = (tile_count > 1 || opt->compact_tiles != 0) ? 1u : 0u;
+    A.shadow_mode = opt->shadow_mode;
     A.n_slots = n_slots;
     A.max_depth = opt->max_depth;
     A.min_contribution = opt->min_contribution;
@@ -941,6 +949,7 @@ int check_frame_args(rt_context* ctx, const rt_scene* scene, const rt_view* view
     if ((uint64_t)view->width * view->height > 0x7fffffffull / 3) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large");
     if (opt->max_depth + 2 > RT_MAX_LEVELS) return fail(ctx, RT_ERR_UNSUPPORTED, "max_depth too large");
     if (opt->fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown fp_mode");
+    if (opt->shadow_mode > RT_SHADOW_ANY_HIT) return fail(ctx, RT_ERR_INVALID, "unknown shadow_mode");
     const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
     if (opt->tile_rank >= tile_count) return fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_count");
     if (scene->dev.n_lights > 65535) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 65535 lights");

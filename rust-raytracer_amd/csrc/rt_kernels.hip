@@ -272,7 +272,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
 // a full closest-hit query ignoring the surface's own primitive, blocked iff its distance
 // <= the light's distance.
 // ---------------------------------------------------------------------------------------
-template <int CULL, class Ctr>
+// OCC: 0 = the reference's full closest-hit walk; 1 = stops once "blocked" is certain (same flag);
+// 2 = stops at any hit before the light (rt_options.shadow_mode).
+template <int CULL, class Ctr, int OCC = 0>
 __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A, uint32_t first_level, uint32_t last_level) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
@@ -290,8 +292,8 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A
         const float4 sd = A.sray_d[i];
         Hit blocker;
         bool blocked = false;
-        if (kd_traverse_closest<CULL>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
-                                lds_stack, ctr))
+        if (kd_traverse_closest<CULL, Ctr, OCC>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w),
+                                                            blocker, lds_stack, ctr, so.w))
             blocked = blocker.dist <= so.w;
         A.sray_blocked[i] = blocked ? 1u : 0u;
     }
@@ -620,6 +622,8 @@ hipError_t init_kernels() {
                          (const void*)k_shadow<0, NoCounters>, (const void*)k_shadow<2, NoCounters>,
                          (const void*)k_intersect<true, 5, NoCounters>, (const void*)k_intersect<false, 6, NoCounters>,
                          (const void*)k_shadow<6, NoCounters>,
+                         (const void*)k_shadow<2, NoCounters, 1>, (const void*)k_shadow<6, NoCounters, 1>,
+                         (const void*)k_shadow<2, NoCounters, 2>, (const void*)k_shadow<6, NoCounters, 2>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -661,6 +665,12 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
     if (work) {
         if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level);
         else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, first_level, last_level);
+    } else if (mode == 2 && A.shadow_mode == 1) {
+        if (lean) hipLaunchKernelGGL((k_shadow<6, NoCounters, 1>), g, b, lds, st, A, first_level, last_level);
+        else hipLaunchKernelGGL((k_shadow<2, NoCounters, 1>), g, b, lds, st, A, first_level, last_level);
+    } else if (mode == 2 && A.shadow_mode == 2) {
+        if (lean) hipLaunchKernelGGL((k_shadow<6, NoCounters, 2>), g, b, lds, st, A, first_level, last_level);
+        else hipLaunchKernelGGL((k_shadow<2, NoCounters, 2>), g, b, lds, st, A, first_level, last_level);
     } else {
         if (mode == 2 && lean) hipLaunchKernelGGL((k_shadow<6, NoCounters>), g, b, lds, st, A, first_level, last_level);
         else if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, first_level, last_level);
@@ -710,6 +720,14 @@ hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, cons
     else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     return hipGetLastError();
 }
+
+#if defined(RT_X_PHASE) && !RT_FAST
+extern "C" int rt_x_phase_cycles(unsigned long long* out8, int reset) {
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 hipError_t launch_debug_eval(uint32_t op, uint64_t n, const float* in, uint32_t is, float* out, uint32_t os,
                              const float4* vpos, const float4* vnrm, uint32_t n_verts, hipStream_t st) {

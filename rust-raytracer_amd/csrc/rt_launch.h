@@ -24,8 +24,12 @@ namespace rtamd {
 
 // Scene as the kernels see it (all device pointers).
 struct DevScene {
-    // 4 x uint4 per node (64 B): {bmin, plane} {bmax, axis}; interior: {under, over, -, -} {-};
-    // leaf (axis 3): {sphere run first, count, cone run first, count} {polygon run first, count, header of the sphere run's bounding records, same of the polygon run or ~0}
+    // 4 x uint4 per node (64 B, one fetch).  Interior: {plane, axis, under, over} then the two
+    // children's boxes {under min xyz, under max x} {under max yz, over min xy} {over min z, over
+    // max xyz} (max = fl(corner + extent), src/shape.rs:37-39): a node's own box is tested from its
+    // parent's record, the root's from root_min / root_max.  Leaf: {header of the cylinder run's
+    // bounding records or ~0, 3, -, -} {sphere run first, count, cone run first, count} {polygon
+    // run first, count, header of the sphere run's bounding records, same of the polygon run or ~0} {-}
     const uint4* nodes;
     // Leaf primitive lists, one run per kind and leaf, each in the builder's list order.
     const float4* sph;         // sphere runs: {centre, r*r}; every run padded to a multiple of 8 entries
@@ -48,6 +52,7 @@ struct DevScene {
     uint32_t stack_depth;      // depth of the tree (>= 1): the most entries a lane's traversal stack can hold
     uint32_t lean;             // 1: no cones and no polygon run with bounding records anywhere in the scene
     float bg[3];
+    float root_min[3], root_max[3];  // the root node's box
 };
 
 struct FrameArgs {
@@ -59,6 +64,7 @@ struct FrameArgs {
     // interleaved tiles
     uint32_t tiles_x, tile_rank, tile_count;
     uint32_t compact;  // outputs are this rank's compact tile buffer (always so when tile_count > 1)
+    uint32_t shadow_mode;  // RT_SHADOW_*: which k_shadow runs (culled walk without counters only)
     uint32_t n_slots;  // level-0 rays: 64 per local tile
     // integrator constants (reference src/scene.rs:8-9)
     uint32_t max_depth;

@@ -30,6 +30,8 @@
 // by all lanes standing on the same leaf together with a wave-uniform index, so that the
 // entries arrive through scalar loads and stay in SGPRs.
 #pragma once
+#include <type_traits>
+
 #include "rt_shapes.h"
 
 namespace RT_NS {
@@ -405,12 +407,103 @@ RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, fl
     leaf_cones<false, BEHIND ? 2 : 1>(S, i0, 8u, src, ray, un, true, near, ignore, lb, ctr);
 }
 
+// A lane's traversal stack.  RING false: entry k at lds[k * stride].  RING true: entries
+// [lo, sp) in the LDS slots k % RT_STACK_RING, entries [0, lo) in private memory; a push into a
+// full ring moves the oldest entry out first, a pop from an empty ring reads the entry back.
+template <bool RING>
+struct KdStack {
+    uint2* lds;
+    uint32_t stride, sp, lo;
+    uint2 deep[RING ? RT_STACK_DEEP : 1];
+    RT_DEV void init(uint2* lane_base, uint32_t lane_stride) { lds = lane_base; stride = lane_stride; sp = 0; lo = 0; }
+    RT_DEV bool empty() const { return sp == 0; }
+    RT_DEV void push(uint2 v) {
+        if constexpr (RING) {
+            if (sp - lo == RT_STACK_RING) {
+                deep[lo] = lds[(lo % RT_STACK_RING) * stride];
+                ++lo;
+            }
+            lds[(sp % RT_STACK_RING) * stride] = v;
+        } else {
+            lds[sp * stride] = v;
+        }
+        ++sp;
+    }
+    RT_DEV uint2 get(uint32_t k) const {  // entry k < sp, left in place
+        if constexpr (RING) {
+            if (k < lo) return deep[k];
+            return lds[(k % RT_STACK_RING) * stride];
+        } else {
+            return lds[k * stride];
+        }
+    }
+    RT_DEV uint2 pop() {
+        --sp;
+        if constexpr (RING) {
+            if (sp < lo) {  // (then lo == sp + 1: the ring is empty)
+                lo = sp;
+                return deep[sp];
+            }
+            return lds[(sp % RT_STACK_RING) * stride];
+        } else {
+            return lds[sp * stride];
+        }
+    }
+};
+
+
+// Shadow rays ask one thing of the closest hit: is it at most `limit` away (src/scene.rs:108-117).
+// That can be known before a leaf is finished, exactly.  Let a hit at t <= limit have been found
+// in the current leaf, with t >= 0 (a shadow ray's near value), and let no pending stack entry
+// send a result at t into its far child (the end-point test of src/space_partition.rs:316-317,
+// :334-335, evaluated here with the very expression the walk uses).  The leaf's final hit is
+// the nearest of its candidates, so it lies at some t' <= t <= limit; and the end-point test is
+// monotone: for an entry on whose near side the origin lies, fl(src + fl(ray t)) moves towards the
+// plane and beyond it as t grows, or (direction pointing away) never gets there for t >= 0; so a
+// result at t' passes every entry that a result at t passes.  The walk would therefore end with
+// that leaf's result, at a distance <= limit: "blocked", whatever the rest of the leaf holds.
+// The traversal stops there and reports t (not the nearest distance, which nobody needs).
+// ANY: the stack is not consulted -- any hit at most `limit` away counts (the usual "any-hit"
+// shadow test).  That is NOT the reference's answer where its walk would have dropped the hit for
+// a far child's result (src/space_partition.rs:313-325): it can only turn lit into shadowed.
+template <bool RING, bool ANY>
+struct Occluder {
+    static constexpr bool kOn = true;
+    const KdStack<RING>* st;
+    F3 src, ray;
+    float limit;    // -inf: never decides
+    float checked;  // a t that did not pass the pending entries (t only shrinks: not tried again)
+    bool hit;
+    RT_DEV void init(const KdStack<RING>* s, F3 o, F3 d, float lim) { st = s; src = o; ray = d; limit = lim; checked = -1.0f; hit = false; }
+    RT_DEV bool decided(const LeafBest& lb) {
+        if (hit) return true;
+        if (!lb.have || !(lb.t <= limit) || lb.t == checked) return false;
+        for (uint32_t k = ANY ? 0u : st->sp; k-- > 0u;) {
+            const uint2 ent = st->get(k);
+            const uint32_t axis = ent.x >> 30;
+            const float plane = __uint_as_float(ent.y);
+            const float endpoint = comp(src, axis) + comp(ray, axis) * lb.t;
+            const bool under_first = comp(src, axis) < plane;
+            if (under_first ? (endpoint > plane) : (endpoint < plane)) {
+                checked = lb.t;
+                return false;
+            }
+        }
+        hit = true;
+        return true;
+    }
+};
+struct NoOccluder {
+    static constexpr bool kOn = false;
+    RT_DEV bool decided(const LeafBest&) { return false; }
+};
+
 // KIND 1: the run holds polygons, KIND 2: cones with equal radii; each is bounded by the sphere
 // polygon_bound / cylinder_bound (leaf_cluster.cpp) derives for it, and the records and their
 // test are the same as for spheres (KIND 0).
-template <int KIND, bool BEHIND, class Ctr>
+template <int KIND, bool BEHIND, class Ctr, class Occ>
 RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, F3 un, float a,
-                          float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride) {
+                          float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride, Occ& occ) {
     const float4 hf = S.bnd[header];
     ctr.bound_tests(1);
     if (!bound_may_hit<BEHIND>(S.bnd[header + 1u], src, un)) return;  // misses the whole run
@@ -435,6 +528,12 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             if constexpr (KIND == 1) polygons8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
             else if constexpr (KIND == 2) cylinders8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
             else cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
+            if constexpr (Occ::kOn) {
+                if (occ.decided(lb)) {  // (a shadow ray that is known to be blocked)
+                    qn = 0u;
+                    return;
+                }
+            }
         }
     };
 
@@ -451,7 +550,12 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
                     ctr.bound_passes((uint32_t)__builtin_popcount(m));
                     lq[(LANE_STACK + qn) * stride] = (g << 8) | m;
                     ++qn;
-                    if (qn == LANE_QUEUE) drain();
+                    if (qn == LANE_QUEUE) {
+                        drain();
+                        if constexpr (Occ::kOn) {
+                            if (occ.hit) return;
+                        }
+                    }
                 }
                 m = 0u;
             }
@@ -485,46 +589,19 @@ RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, F3 
     if (q3.y) leaf_polygons<U, BND>(S, q3.x, q3.y, src, ray, un, ok_poly, near, ignore, lb, ctr);
 }
 
-// A lane's traversal stack.  RING false: entry k at lds[k * stride].  RING true: entries
-// [lo, sp) in the LDS slots k % RT_STACK_RING, entries [0, lo) in private memory; a push into a
-// full ring moves the oldest entry out first, a pop from an empty ring reads the entry back.
-template <bool RING>
-struct KdStack {
-    uint2* lds;
-    uint32_t stride, sp, lo;
-    uint2 deep[RING ? RT_STACK_DEEP : 1];
-    RT_DEV void init(uint2* lane_base, uint32_t lane_stride) { lds = lane_base; stride = lane_stride; sp = 0; lo = 0; }
-    RT_DEV bool empty() const { return sp == 0; }
-    RT_DEV void push(uint2 v) {
-        if constexpr (RING) {
-            if (sp - lo == RT_STACK_RING) {
-                deep[lo] = lds[(lo % RT_STACK_RING) * stride];
-                ++lo;
-            }
-            lds[(sp % RT_STACK_RING) * stride] = v;
-        } else {
-            lds[sp * stride] = v;
-        }
-        ++sp;
-    }
-    RT_DEV uint2 pop() {
-        --sp;
-        if constexpr (RING) {
-            if (sp < lo) {  // (then lo == sp + 1: the ring is empty)
-                lo = sp;
-                return deep[sp];
-            }
-            return lds[(sp % RT_STACK_RING) * stride];
-        } else {
-            return lds[sp * stride];
-        }
-    }
-};
+// Stack entry of an interior node whose far child is still to be decided on:
+//   x = far child | FAR_BOX_HIT if the ray passes the far child's box | axis << 30,  y = bits(plane).
+// The far child's box sits in its parent's record (below), so it is tested while that record is at
+// hand; the test has no side effect, so doing it before the reference would changes nothing.
+constexpr uint32_t FAR_BOX_HIT = 1u << 29;
+constexpr uint32_t FAR_CHILD_MASK = FAR_BOX_HIT - 1u;
 
 // Result of a finished subtree against the pending stack entries: returns true and sets
-// `cur` when some entry sends the walk into its far child, false when the walk is over.
-template <bool RING>
-RT_DEV bool unwind(KdStack<RING>& st, F3 src, F3 ray, bool& r_hit, float r_dist, uint32_t& cur) {
+// `cur` when some entry sends the walk into its far child (whose box the ray is known to pass),
+// false when the walk is over.  A far child whose box is missed is a visit that returns none
+// (src/space_partition.rs:276-279): the walk goes on popping with no result.
+template <bool RING, class Ctr>
+RT_DEV bool unwind(KdStack<RING>& st, F3 src, F3 ray, bool& r_hit, float r_dist, uint32_t& cur, Ctr& ctr) {
     while (!st.empty()) {
         const uint2 ent = st.pop();
         const uint32_t axis = ent.x >> 30;
@@ -536,22 +613,41 @@ RT_DEV bool unwind(KdStack<RING>& st, F3 src, F3 ray, bool& r_hit, float r_dist,
             take_second = under_first ? (endpoint > plane) : (endpoint < plane);
         }
         if (take_second) {
-            cur = ent.x & 0x3fffffffu;
+            ctr.node_visits(1);
             r_hit = false;
-            return true;
+            if ((ent.x & FAR_BOX_HIT) != 0u) {
+                cur = ent.x & FAR_CHILD_MASK;
+                return true;
+            }
         }
     }
     return false;
 }
+
+#ifdef RT_X_PHASE  // (timing experiment: wave cycles per phase of the walk, summed over waves)
+__device__ unsigned long long g_phase[8];
+#define RT_PHASE_T0() unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[6] = {0, 0, 0, 0, 0, 0}
+#define RT_PHASE(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); ph_acc[k] += now_ - ph_t; ph_t = now_; } while (0)
+#define RT_PHASE_END() do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true))) { \
+        for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_phase[k_], ph_acc[k_]); atomicAdd(&g_phase[7], 1ull); } } while (0)
+#else
+#define RT_PHASE_T0() do {} while (0)
+#define RT_PHASE(k) do {} while (0)
+#define RT_PHASE_END() do {} while (0)
+#endif
 
 // CULL: 0 = every entry of every visited leaf, 1 = big runs skip groups the ray's line misses,
 // 2 = also groups behind the ray's origin (worth its cost for rays that start inside the
 // scene); + 4 = the scene has neither cones nor polygon runs with bounding records, and the
 // kernel carries no code for them (kilobytes less for the instruction cache, which the
 // intersect and shadow kernels of a frame share).
-template <int CULL, class Ctr>
+// OCC != 0 (shadow rays; needs near == 0): `limit` is the distance that matters, and the walk stops
+// as soon as the answer "a hit at most that far" is certain (1, Occluder) or as soon as any such
+// hit is found (2, not the reference's answer in every case); out.dist is then some distance <=
+// limit, not the nearest.
+template <int CULL, class Ctr, int OCC = 0>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
-                                uint2* stack, Ctr& ctr) {
+                                uint2* stack, Ctr& ctr, float limit = 0.0f) {
     RayInv ri;
     ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
     {
@@ -572,6 +668,9 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     const bool tame = a >= 1e-30f && a < 1e16f && dot(src, src) < 1e16f && (MODE != 2 || near >= 0.0f);
     F3 un = ray;
     if constexpr (MODE != 0) un = unit_ray(ray, a);
+    constexpr bool OCCL = OCC != 0;
+    typename std::conditional<OCCL, Occluder<!LEAN, OCC == 2>, NoOccluder>::type occ;
+    if constexpr (OCCL) occ.init(&st, src, ray, (tame && near == 0.0f && limit < 1e30f) ? limit : -INFINITY);
     constexpr int BND = LEAN ? 0 : MODE;  // (a lean scene has no cones and next to no polygons)
     const bool ok_cone = tame && near >= 0.0f;
     uint32_t cur = 0;
@@ -580,45 +679,59 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
     Hit r;
     r.dist = 0.0f; r.prim = NO_PRIM; r.n = f3(0.0f, 0.0f, 0.0f);
 
+    RT_PHASE_T0();
+    // A node's record holds its children's boxes: one fetch per interior node on the path, both
+    // children's box tests from it, and no fetch at all for a child whose box the ray misses.
+    auto box_hit = [&](F3 bmin, F3 bmax) -> bool {
+#if RT_FAST
+        return aabb_slab_test(bmin, bmax, src, ray, near, ri);
+#else
+        // the reference's six divisions only where the quotients' order is in doubt
+        bool in_box = false;
+        if (!ri.quick || !aabb_quick(bmin, bmax, src, ray, near, ri.inv, in_box)) in_box = aabb_slab_test(bmin, bmax, src, ray, near, ri);
+        return in_box;
+#endif
+    };
+    ctr.node_visits(1);
+    if (!box_hit(f3(S.root_min[0], S.root_min[1], S.root_min[2]), f3(S.root_max[0], S.root_max[1], S.root_max[2]))) done = true;  // :276-279
     while (!done) {
         // ---- walk until this lane stands on a leaf whose box it hits, or is finished
         bool at_leaf = false;
-        uint32_t leaf_w = 0xffffffffu;  // a leaf's fourth word: header of its cylinder run's records, or none
+        uint32_t leaf_w = 0xffffffffu;  // a leaf's first word: header of its cylinder run's records, or none
         uint4 q2 = make_uint4(0, 0, 0, 0), q3 = make_uint4(0, 0, 0, 0);
         while (!done && !at_leaf) {
-            const uint4 q0 = S.nodes[cur * 4 + 0];
-            const uint4 q1 = S.nodes[cur * 4 + 1];
-            ctr.node_visits(1);
-            const F3 bmin = f3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-            const F3 bmax = f3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
-#if RT_FAST
-            const bool in_box = aabb_slab_test(bmin, bmax, src, ray, near, ri);
-#else
-            // the reference's six divisions only where the quotients' order is in doubt
-            bool in_box = false;
-            if (!ri.quick || !aabb_quick(bmin, bmax, src, ray, near, ri.inv, in_box))
-                in_box = aabb_slab_test(bmin, bmax, src, ray, near, ri);
-#endif
-            if (in_box) {  // :276-279
-                q2 = S.nodes[cur * 4 + 2];
-                const uint32_t axis = q1.w;
-                if (axis == AXIS_LEAF) {
-                    q3 = S.nodes[cur * 4 + 3];
-                    leaf_w = q0.w;
-                    at_leaf = true;
-                } else {
-                    ctr.interior_steps(1);
-                    const float plane = __uint_as_float(q0.w);
-                    const bool under_first = comp(src, axis) < plane;  // :303
-                    st.push(make_uint2((under_first ? q2.y : q2.x) | (axis << 30), q0.w));
-                    cur = under_first ? q2.x : q2.y;
-                }
+            const uint4 n0 = S.nodes[cur * 4 + 0];
+            const uint4 n1 = S.nodes[cur * 4 + 1];
+            const uint4 n2 = S.nodes[cur * 4 + 2];
+            const uint4 n3 = S.nodes[cur * 4 + 3];
+            const uint32_t axis = n0.y;
+            if (axis == AXIS_LEAF) {
+                q2 = n1;
+                q3 = n2;
+                leaf_w = n0.x;
+                at_leaf = true;
             } else {
-                r_hit = false;
-                if (!unwind(st, src, ray, r_hit, r.dist, cur)) done = true;
+                ctr.interior_steps(1);
+                const float plane = __uint_as_float(n0.x);
+                const bool under_first = comp(src, axis) < plane;  // :303
+                const F3 umin = f3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z));
+                const F3 umax = f3(__uint_as_float(n1.w), __uint_as_float(n2.x), __uint_as_float(n2.y));
+                const F3 omin = f3(__uint_as_float(n2.z), __uint_as_float(n2.w), __uint_as_float(n3.x));
+                const F3 omax = f3(__uint_as_float(n3.y), __uint_as_float(n3.z), __uint_as_float(n3.w));
+                const bool hit_u = box_hit(umin, umax), hit_o = box_hit(omin, omax);
+                const bool hit_first = under_first ? hit_u : hit_o, hit_second = under_first ? hit_o : hit_u;
+                st.push(make_uint2((under_first ? n0.w : n0.z) | (hit_second ? FAR_BOX_HIT : 0u) | (axis << 30), n0.x));
+                ctr.node_visits(1);  // the first child is visited whatever its box says
+                if (hit_first) {
+                    cur = under_first ? n0.z : n0.w;
+                } else {
+                    r_hit = false;
+                    if (!unwind(st, src, ray, r_hit, r.dist, cur, ctr)) done = true;
+                }
             }
         }
 
+        RT_PHASE(0);  // node walk
         if (at_leaf) {
             LeafBest lb;
             lb.init();
@@ -628,24 +741,30 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
             }
             if constexpr (MODE != 0) {
                 if (q2.y >= CULL_MIN_SPHERES && tame) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_run_lane<0, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride);
+                    leaf_run_lane<0, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ);
                     q2.y = 0u;
                 }
+                RT_PHASE(1);  // sphere hierarchy
                 if constexpr (!LEAN) {
-                    if (q3.w != 0xffffffffu && tame) {  // polygon run with bounding records
-                        leaf_run_lane<1, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride);
+                    if (q3.w != 0xffffffffu && tame && !occ.decided(lb)) {  // polygon run with bounding records
+                        leaf_run_lane<1, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ);
                         q3.y = 0u;
                     }
-                    if (cyl_n != 0u && tame && near >= 0.0f) {  // cylinder run with bounding records
+                    RT_PHASE(2);  // polygon hierarchy
+                    if (cyl_n != 0u && tame && near >= 0.0f && !occ.decided(lb)) {  // cylinder run with bounding records
                         leaf_run_lane<2, MODE == 2>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, un, a, near, ignore, lb, ctr,
-                                                    lane_words, stride);
+                                                    lane_words, stride, occ);
                         cyl_n = 0u;
                     }
+                    RT_PHASE(3);  // cylinder hierarchy
                 }
             }
             if constexpr (!LEAN) {  // cylinders not walked above go with the cones, which they precede
                 q2.z -= cyl_n;
                 q2.w += cyl_n;
+            }
+            if constexpr (OCCL) {
+                if (occ.decided(lb)) q2.y = q2.w = q3.y = 0u;  // blocked for certain: nothing left to look at
             }
             // What is left (short runs, cones, rays the bounding test cannot take): entry by entry.
             // Long lists are walked by all lanes standing on the same leaf together, index
@@ -678,20 +797,28 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
             } else {
                 leaf_runs<false, BND, MODE != 0>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
             }
+            RT_PHASE(4);  // short runs, cones proper
             r_hit = lb.have;
             if (lb.have) {
                 r.dist = lb.t;
                 r.prim = lb.prim;
-                if (lb.sphere != NO_PRIM) {
-                    const float4 s = S.sph[lb.sphere];
-                    r.n = sphere_normal(f3(s.x, s.y, s.z), src, ray, lb.t);
-                } else {
-                    r.n = lb.n;
+                if constexpr (!OCCL) {  // (a shadow ray's normal is of no use)
+                    if (lb.sphere != NO_PRIM) {
+                        const float4 s = S.sph[lb.sphere];
+                        r.n = sphere_normal(f3(s.x, s.y, s.z), src, ray, lb.t);
+                    } else {
+                        r.n = lb.n;
+                    }
                 }
             }
-            if (!unwind(st, src, ray, r_hit, r.dist, cur)) done = true;
+            bool stop_here = false;
+            if constexpr (OCCL) stop_here = occ.decided(lb);
+            if (stop_here) done = true;
+            else if (!unwind(st, src, ray, r_hit, r.dist, cur, ctr)) done = true;
+            RT_PHASE(5);  // result + unwind
         }
     }
+    RT_PHASE_END();
     out = r;
     return r_hit;
 }

@@ -549,3 +549,42 @@ def test_tile_gather_over_rccl_with_one_rank(rtamd, oracle, gpu_ctx):
         assert np.array_equal(tg.image.cpu().numpy(), ou)
     finally:
         dist.destroy_process_group()
+
+
+SHADOW_SCENES = ("balls", dict(size=3), 8), ("rings", dict(size=3), 8), ("mount", dict(size=5, lights=6), 6), ("lathe", dict(nu=32, nv=16), 5)
+
+
+@pytest.mark.parametrize("gen,kw,depth", SHADOW_SCENES)
+def test_shadow_modes(rtamd, oracle, spd, gpu_ctx, gen, kw, depth):
+    """RT_SHADOW_EXACT_STOP ends a shadow ray's walk once "blocked" is certain: same flags, so the
+    same frame to the bit and the same ray counts as the reference's full walk.
+    RT_SHADOW_ANY_HIT (the opt-in fast shadows, not a parity mode) stops at any hit before the
+    light.  Its flag can differ from the reference's (src/scene.rs:108-117) only where the
+    reference's traversal drops a hit for its far child's result (src/space_partition.rs:313-325),
+    and then only from lit to shadowed: it traces the same rays, no channel of its frame is brighter
+    than the reference's, and few pixels differ at all."""
+    w, h = 320, 240
+    text = spd.GENERATORS[gen](width=w, height=h, **kw)
+    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=4)
+    of, ou, octr, _ = oracle.OracleScene(text, build_threads=4).render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, threads=8)
+    f0, u0, s0 = sc.render(rtamd.RenderOptions(max_depth=depth), w, h)
+    assert np.array_equal(bits(f0), bits(of))
+    f1, u1, s1 = sc.render(rtamd.RenderOptions(max_depth=depth, shadow_mode=rtamd.SHADOW_EXACT_STOP), w, h)
+    assert np.array_equal(bits(f1), bits(of)) and np.array_equal(u1, ou)
+    f2, u2, s2 = sc.render(rtamd.RenderOptions(max_depth=depth, shadow_mode=rtamd.SHADOW_ANY_HIT), w, h)
+    for k in RAY_KEYS:
+        assert s1.as_dict()[k] == octr[k] and s2.as_dict()[k] == octr[k], k
+    assert (f2 <= f0).all()
+    differing = float((bits(f2) != bits(f0)).any(axis=2).mean())
+    assert differing < 0.01, differing
+
+
+def test_any_hit_shadows_equal_the_reference_without_interior_nodes(rtamd, gpu_ctx):
+    """With the whole scene in one leaf no hit is ever dropped, so any-hit shadows are the reference's."""
+    for name in ("test-shadow-1", "test-shadow-2", "test-overlap", "extra-cones"):
+        sc = rtamd.Scene.from_nff(gpu_ctx, read_nff(name))
+        if sc.tree_info.n_nodes != 1:
+            continue
+        f0, _, _ = sc.render(rtamd.RenderOptions(), 256, 256)
+        f2, _, _ = sc.render(rtamd.RenderOptions(shadow_mode=rtamd.SHADOW_ANY_HIT), 256, 256)
+        assert np.array_equal(bits(f0), bits(f2)), name
