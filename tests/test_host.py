@@ -219,3 +219,60 @@ def test_ppm_writer(rtamd, tmp_path):
     rtamd.write_ppm(path, img)
     data = open(path, "rb").read()
     assert data == b"P6\n7 5\n255\n" + img.tobytes()  # reference src/ppm.rs:12-25
+
+
+def test_header_is_plain_c_and_host_entry_points_work_from_c(rtamd, oracle, tmp_path):
+    """tests/native/abi_smoke.c: include/rtamd.h compiled as C99 with -Wall -Wextra -Werror -pedantic
+    (what bindgen or a C host would see), then parse -> tree build -> camera basis -> tile math ->
+    PPM writer called from C; struct sizes as C sees them equal the ctypes mirror's."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(rtamd.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "native", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lrtamd",
+                    "-Wl,-rpath," + libdir], check=True, capture_output=True)
+    nff = os.path.join(NFF_DIR, "extra-onplane.nff")
+    out = str(tmp_path / "o.ppm")
+    r = subprocess.run([exe, nff, out], check=True, capture_output=True, text=True)
+    sizes_line, built = r.stdout.strip().splitlines()
+    tok = sizes_line.split()
+    sizes = {tok[i]: int(tok[i + 1]) for i in range(1, len(tok), 2)}
+    for name in ("rt_view", "rt_sphere", "rt_cone", "rt_vertex", "rt_polygon", "rt_surface", "rt_light", "rt_primitive",
+                 "rt_kd_node", "rt_scene_desc", "rt_options", "rt_stats", "rt_tree_info"):
+        assert sizes[name] == C.sizeof(getattr(rtamd, name)), name
+    kv = built.split()
+    got = {kv[i]: kv[i + 1] for i in range(0, len(kv) - 3, 2) if kv[i] != "forward"}
+    p = rtamd.ParsedScene(open(nff, "rb").read())
+    info, nodes, refs = p.build_tree()
+    assert int(got["primitives"]) == p.desc.n_primitives and int(got["nodes"]) == info.n_nodes
+    assert int(got["leaf_refs"]) == info.n_leaf_refs and int(got["depth"]) == info.max_depth
+    assert int(got["root_axis"]) == nodes[0]["axis"]
+    assert int(got["tile_slots"]) == sum(rtamd.tile_pixels(p.view.width, p.view.height, r_, 3) for r_ in range(3))
+    data = open(out, "rb").read()
+    assert data.startswith(b"P6\n%d %d\n255\n" % (p.view.width, p.view.height))
+
+
+def test_rust_sys_crate_mirrors_the_header(rtamd):
+    """rtamd-sys/src/lib.rs (the FFI crate a Rust host links; it cannot be compiled in this image)
+    declares every function of include/rtamd.h and lists every struct's fields in the header's order."""
+    header = open(os.path.join(ROOT, "include", "rtamd.h")).read()
+    rs = open(os.path.join(ROOT, "rtamd-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", header))
+    bound = set(re.findall(r"pub fn (rt_[a-z_0-9]+)\s*\(", rs))
+    assert declared == bound, (declared - bound, bound - declared)
+    plain = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for m in re.finditer(r"typedef struct (rt_[a-z_]+) \{(.*?)\} \1;", plain, flags=re.S):
+        name, body = m.group(1), m.group(2)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                fields.append(re.sub(r"\[.*?\]", "", part).replace("*", " ").split()[-1])
+        rm = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S)
+        assert rm, name
+        rfields = re.findall(r"pub ([a-z_0-9]+):", rm.group(1))
+        assert rfields == fields, (name, fields, rfields)
+    for const in re.findall(r"\b(RT_[A-Z_0-9]+) = ", plain):
+        assert ("pub const %s:" % const) in rs, const
