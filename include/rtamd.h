@@ -119,7 +119,11 @@ typedef struct rt_scene_desc {
 
 enum {
     RT_FP_EXACT = 0, /* no FMA contraction, IEEE divide/sqrt, reference operation order */
-    RT_FP_FAST = 1   /* FMA contraction, reciprocal slab test, hardware pow */
+    RT_FP_FAST = 1   /* FMA contraction, reciprocal slab test, hardware pow.  NOT a parity mode: within 1 LSB on
+                        >= 99.9 % of pixels only on scenes without chains of curved mirrors or glass; on
+                        sphereflake- or rings-like scenes a few tenths of a percent to a few percent of
+                        pixels differ by more (any change of rounding decorrelates a path after a few
+                        bounces), so it is outside the tolerance there */
 };
 
 /* How a shadow ray decides "blocked" (reference src/scene.rs:108-117: a full closest-hit query,

@@ -68,7 +68,7 @@ struct Workspace {
     uint32_t *hit_p = nullptr, *sray_blocked = nullptr;
     uint2* node_sh = nullptr;
     uint4* node_kid = nullptr;
-    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_count[RT_MAX_LEVELS] | overflow
+    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_count[RT_MAX_LEVELS] | overflow | work_next[2 * RT_MAX_LEVELS]
     uint32_t* levels = nullptr;
     unsigned long long* counters = nullptr;
     size_t pool_cap = 0;    // ray-tree nodes
@@ -163,7 +163,8 @@ struct rt_scene {
 
 namespace {
 
-constexpr uint32_t LV_SHADOW_COUNT = 2 * RT_MAX_LEVELS, LV_OVERFLOW = 3 * RT_MAX_LEVELS, LV_WORDS = 3 * RT_MAX_LEVELS + 1;
+constexpr uint32_t LV_SHADOW_COUNT = 2 * RT_MAX_LEVELS, LV_OVERFLOW = 3 * RT_MAX_LEVELS, LV_WORK_NEXT = 3 * RT_MAX_LEVELS + 1,
+                   LV_WORDS = 5 * RT_MAX_LEVELS + 1;
 constexpr uint32_t N_COUNTERS = 40;  // see FrameArgs::counters
 constexpr uint32_t SHADOW_GROUP_FROM = 4;  // levels from here on are too small to fill the GPU: one shadow launch for all
 
@@ -598,7 +599,13 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.n_lights = (uint32_t)sd.lights.size();
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
     // lean: no cones and next to no polygons (a floor): kernels without the code for either's records
-    d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8 && d.stack_depth <= RT_STACK_RING) ? 1u : 0u;
+    d.bnd_records = (uint32_t)(bnd.size() / 4);
+    d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8 && d.stack_depth <= RT_STACK_RING &&
+              bnd.size() * sizeof(float) <= RT_LEAN_RECORD_BYTES) ? 1u : 0u;
+    // Measured at 3840x2160 (k_shadow, ms, lanes waiting for their wave / lanes taking the next ray): rings 4
+    // (largest leaf 212) 23.1 / 18.4; lathe 96 at 1920x1080 (273) 2.41 / 2.34; mount 8 (45685) 6.4 / 8.0;
+    // balls 4 (lean) 2.79 / 3.44.
+    d.refill = (d.lean == 0u && sc->tree.info.max_leaf < 1024u) ? 1u : 0u;
     memcpy(d.bg, sd.background, sizeof(d.bg));
     memcpy(d.root_min, sc->tree.nodes[0].bmin, sizeof(d.root_min));
     memcpy(d.root_max, sc->tree.nodes[0].bmax, sizeof(d.root_max));
@@ -680,7 +687,8 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     const uint32_t tile_count = opt->tile_count ? opt->tile_count : 1;
     const TileGrid grid(view->width, view->height, tile_count);
     const uint32_t n_slots = p.n_slots, n_lights = p.n_lights;
-    if (cap > 0xfffffff0ull || scap * p.lights1 > 0xfffffff0ull)
+    // (room above the largest index: the work counters of the lean kernels run past their ends by 512 per wave)
+    if (cap > 0xf0000000ull || scap * p.lights1 > 0xf0000000ull)
         return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
     if (!f.fixed && ctx->workspace_limit != 0 &&
         (uint64_t)std::max(cap, f.ws.pool_cap) * NODE_BYTES + (uint64_t)std::max(scap * p.lights1, f.ws.shadow_cap) * SHADOW_BYTES >
@@ -732,6 +740,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.level_base = ws.levels + RT_MAX_LEVELS;
     A.shadow_count = ws.levels + LV_SHADOW_COUNT;
     A.overflow = ws.levels + LV_OVERFLOW;
+    A.work_next = ws.levels + LV_WORK_NEXT;
     A.counters = ws.counters;
 
     // Levels that cannot hold a ray are not launched.  A ray of level k carries a contribution of

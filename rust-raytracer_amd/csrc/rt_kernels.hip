@@ -27,12 +27,24 @@
 #include "rt_traverse.h"
 #include "rt_launch.h"
 
+#ifndef RT_SHADOW_WAVES
+#define RT_SHADOW_WAVES RT_TRACE_WAVES  // waves per SIMD the shadow kernels are compiled for
+#endif
+
 namespace RT_NS {
 
 using rtamd::DeinterleaveArgs;
 using rtamd::FrameArgs;
 
 constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t RT_MAX_BLOCK_WAVES = 16u;
+#ifndef RT_SHADOW_REFILL
+#define RT_SHADOW_REFILL 16  // idle lanes of a shadow wave at which they take new rays (0: a wave traces 64 rays at a time)
+#endif
+#ifndef RT_SHADOW_CHUNK
+#define RT_SHADOW_CHUNK 512u  // consecutive shadow rays a wave owns at a time, at most (fewer in small launches)
+#endif
+constexpr uint32_t LEAN_TAKE = 512u;  // rays a wave of a lean kernel takes from the launch's counter at a time
 
 RT_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -135,21 +147,48 @@ RT_DEV uint32_t shadow_first(const FrameArgs& A, uint32_t level) {
 // k_intersect: closest hit of every ray of one level, its shadow rays, and the rays it spawns
 // ---------------------------------------------------------------------------------------
 template <bool LEVEL0, int CULL, class Ctr>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArgs A, uint32_t level) {
+__global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArgs A, uint32_t level) {
     extern __shared__ uint2 lds_stack[];
+    __shared__ uint32_t block_ask[2][3 * RT_MAX_BLOCK_WAVES + 2];  // the waves' counts (lit, spawned, reflected), then the block's two first slots
     const DevScene& S = A.scene;
     const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
     const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
     const uint32_t next_base = base + count;
     if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = next_base;
+    if constexpr ((CULL & 8) != 0) {
+        if (A.work_next[level] >= count) return;  // (a block that comes when the level is used up; the same for all its threads)
+        stage_records(S, lds_stack);
+    }
     const uint32_t n_lights = S.n_lights;
     const uint32_t sh_base = shadow_first(A, level);
     Ctr ctr;
-    uint32_t n_refl = 0, n_refr = 0;
+    uint32_t n_refl = 0, n_refr = 0;        // rays appended, counted by lane ...
+    uint32_t block_refl = 0, block_refr = 0, step = 0;  // ... or by the block's first thread, for all of its waves
 
-    // (blockDim.x, not RT_BLOCK: the trace kernels of scenes with small leaves run in smaller blocks)
-    for (uint32_t chunk = blockIdx.x * blockDim.x; chunk < count; chunk += gridDim.x * blockDim.x) {
-        const uint32_t i = chunk + threadIdx.x;
+    // Lean kernels: a wave takes the next 64 rays of the level until none are left.  The others stride
+    // over the level (blockDim.x, not RT_BLOCK: scenes with small leaves run in smaller blocks).
+    constexpr bool LEAN = (CULL & 8) != 0;  // (the staying blocks of a lean scene's deeper levels)
+    // Queue appends: by every wave for itself, or by all waves of a block together (below).  Staying
+    // blocks' waves take rays on their own and have no common step to meet at.
+    const bool by_wave = LEAN || blockDim.x <= 64u;
+    // (rays per visit to the counter: few where a level is small, so that every wave gets some; more on
+    // big levels, where one address would not take an atomic per 64 rays fast enough)
+    const uint32_t lean_take = count >= (1u << 22) ? LEAN_TAKE : 64u;
+    uint32_t lean_next = 0, lean_left = 0;
+    for (uint32_t chunk = LEAN ? 0u : blockIdx.x * blockDim.x; LEAN || chunk < count; chunk += gridDim.x * blockDim.x) {
+        uint32_t i = chunk + threadIdx.x;
+        if constexpr (LEAN) {
+            if (lean_left == 0u) {
+                uint32_t c = 0;
+                if (lane_id() == 0) c = atomicAdd(&A.work_next[level], lean_take);
+                lean_next = __builtin_amdgcn_readfirstlane(c);
+                lean_left = lean_take;
+            }
+            if (lean_next >= count) break;
+            i = lean_next + lane_id();
+            lean_next += 64u;
+            lean_left -= 64u;
+        }
         const uint32_t node = base + i;
         Ray ray;
         ray.src = f3(0, 0, 0); ray.dir = f3(1, 0, 0); ray.near = 0.0f; ray.contribution = 0.0f; ray.ignore = NO_PRIM;
@@ -170,37 +209,6 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
             }
         }
         const F3 pos = add(ray.src, mul(ray.dir, hit.dist));  // src/scene.rs:95
-
-        // ---- one shadow ray per light for every front-face hit.  Each light has its own queue
-        // (a slice of the arrays, shadow_cap slots long) and a hit uses the same slot in all of
-        // them, so that 64 consecutive slots of a queue are rays towards one light from
-        // neighbouring hits.
-        const uint64_t m_lit = __ballot(lit);
-        const uint32_t c_lit = (uint32_t)__popcll(m_lit);
-        if (c_lit) {
-            uint32_t slot0 = 0;
-            if (lane_id() == 0) slot0 = sh_base + atomicAdd(&A.shadow_count[level], c_lit);
-            slot0 = __builtin_amdgcn_readfirstlane(slot0);
-            if (lit) {
-                const uint32_t first = slot0 + prefix_count(m_lit);
-                const bool fits = slot0 + c_lit <= A.shadow_cap;
-                if (!fits) *A.overflow = 1u;
-                A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
-                if (fits) {
-                    for (uint32_t l = 0; l < n_lights; ++l) {  // src/scene.rs:103-112
-                        ctr.light_evals(1);
-                        const float4 lp = S.lights[l * 2];
-                        const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
-                        const float ldist = magnitude(to_light);
-                        const F3 ldir = divs(to_light, ldist);
-                        const uint64_t s = (uint64_t)l * A.shadow_cap + first;
-                        A.sray_o[s] = make_float4(pos.x, pos.y, pos.z, ldist);
-                        A.sray_d[s] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(hit.prim));
-                    }
-                }
-            }
-        }
-        if (i < count && !lit) A.node_sh[node] = make_uint2(NONE, 0u);  // also the padding slots of edge tiles
 
         // ---- the rays this hit spawns (src/scene.rs:127-193); the node keeps {background or 0,
         // reflectance weight} and the child links, k_light adds the direct light later
@@ -227,29 +235,99 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
                 refr_ray = back_face ? refract(ray.dir, neg(hit.n), 1.0f / surf.ior) : refract(ray.dir, hit.n, surf.ior);
             }
         }
-        // append to the next level: reflection slots first, then refraction
+
+        // ---- room in the shadow queue (one slot per front-face hit) and in the next level (reflection
+        // slots first, then refraction).  An add on one counter takes the memory system 11 ns whoever
+        // sends it (tools/micro/atomic_rate.hip): one per wave would be 1.5 ms for the 130 000 waves of a
+        // 3840x2160 level, so the waves of a block ask together, through LDS, once per block.
+        const uint64_t m_lit = __ballot(lit);
         const uint64_t m_refl = __ballot(want_refl);
         const uint64_t m_refr = __ballot(want_refr);
+        const uint32_t c_lit = (uint32_t)__popcll(m_lit);
         const uint32_t c_refl = (uint32_t)__popcll(m_refl), c_refr = (uint32_t)__popcll(m_refr);
-        uint32_t refl_idx = NONE, refr_idx = NONE;
-        if (c_refl + c_refr) {
-            uint32_t slot0 = 0;
-            if (lane_id() == 0) slot0 = atomicAdd(&A.level_count[level + 1], c_refl + c_refr);
-            slot0 = __builtin_amdgcn_readfirstlane(slot0);
-            if (want_refl) refl_idx = next_base + slot0 + prefix_count(m_refl);
-            if (want_refr) refr_idx = next_base + slot0 + c_refl + prefix_count(m_refr);
-            // The pool is finite: a ray that does not fit is dropped and the frame is flagged
-            // so that the host re-runs it with a larger pool.
-            if (want_refl && refl_idx >= A.pool_cap) { refl_idx = NONE; want_refl = false; *A.overflow = 1u; }
-            if (want_refr && refr_idx >= A.pool_cap) { refr_idx = NONE; want_refr = false; *A.overflow = 1u; }
+        uint32_t lit0 = 0, spawn0 = 0;  // this wave's first shadow slot (before sh_base) and first slot of the next level
+        if (!by_wave) {
+            uint32_t* mine = block_ask[step & 1u];  // (two sets: a wave may be a step ahead of another)
+            ++step;
+            const uint32_t w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+            if (lane_id() == 0) {
+                mine[w] = c_lit;
+                mine[RT_MAX_BLOCK_WAVES + w] = c_refl + c_refr;
+                mine[2 * RT_MAX_BLOCK_WAVES + w] = c_refl;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t t_lit = 0, t_spawn = 0, t_refl = 0;
+                for (uint32_t j = 0; j < nw; ++j) {
+                    t_lit += mine[j];
+                    t_spawn += mine[RT_MAX_BLOCK_WAVES + j];
+                    t_refl += mine[2 * RT_MAX_BLOCK_WAVES + j];
+                }
+                mine[3 * RT_MAX_BLOCK_WAVES] = t_lit ? atomicAdd(&A.shadow_count[level], t_lit) : 0u;
+                const uint32_t at = t_spawn ? atomicAdd(&A.level_count[level + 1], t_spawn) : 0u;
+                mine[3 * RT_MAX_BLOCK_WAVES + 1] = at;
+                // (the block's ray statistics: what fits the pool; an attempt that overflows is run again)
+                const uint32_t room = next_base + at < A.pool_cap ? A.pool_cap - (next_base + at) : 0u;
+                if (t_spawn <= room) {
+                    block_refl += t_refl;
+                    block_refr += t_spawn - t_refl;
+                }
+            }
+            __syncthreads();
+            lit0 = mine[3 * RT_MAX_BLOCK_WAVES];
+            spawn0 = mine[3 * RT_MAX_BLOCK_WAVES + 1];
+            for (uint32_t j = 0; j < w; ++j) {
+                lit0 += mine[j];
+                spawn0 += mine[RT_MAX_BLOCK_WAVES + j];
+            }
+        } else {
+            if (lane_id() == 0) {
+                if (c_lit) lit0 = atomicAdd(&A.shadow_count[level], c_lit);
+                if (c_refl + c_refr) spawn0 = atomicAdd(&A.level_count[level + 1], c_refl + c_refr);
+            }
+            lit0 = __builtin_amdgcn_readfirstlane(lit0);
+            spawn0 = __builtin_amdgcn_readfirstlane(spawn0);
         }
+
+        // ---- one shadow ray per light for every front-face hit.  Each light has its own queue
+        // (a slice of the arrays, shadow_cap slots long) and a hit uses the same slot in all of
+        // them, so that 64 consecutive slots of a queue are rays towards one light from
+        // neighbouring hits.
+        if (lit) {
+            const uint32_t slot0 = sh_base + lit0;
+            const uint32_t first = slot0 + prefix_count(m_lit);
+            const bool fits = slot0 + c_lit <= A.shadow_cap;
+            if (!fits) *A.overflow = 1u;
+            A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
+            if (fits) {
+                for (uint32_t l = 0; l < n_lights; ++l) {  // src/scene.rs:103-112
+                    ctr.light_evals(1);
+                    const float4 lp = S.lights[l * 2];
+                    const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
+                    const float ldist = magnitude(to_light);
+                    const F3 ldir = divs(to_light, ldist);
+                    const uint64_t s = (uint64_t)l * A.shadow_cap + first;
+                    A.sray_o[s] = make_float4(pos.x, pos.y, pos.z, ldist);
+                    A.sray_d[s] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(hit.prim));
+                }
+            }
+        }
+        if (i < count && !lit) A.node_sh[node] = make_uint2(NONE, 0u);  // also the padding slots of edge tiles
+
+        uint32_t refl_idx = NONE, refr_idx = NONE;
+        if (want_refl) refl_idx = next_base + spawn0 + prefix_count(m_refl);
+        if (want_refr) refr_idx = next_base + spawn0 + c_refl + prefix_count(m_refr);
+        // The pool is finite: a ray that does not fit is dropped and the frame is flagged
+        // so that the host re-runs it with a larger pool.
+        if (want_refl && refl_idx >= A.pool_cap) { refl_idx = NONE; want_refl = false; *A.overflow = 1u; }
+        if (want_refr && refr_idx >= A.pool_cap) { refr_idx = NONE; want_refr = false; *A.overflow = 1u; }
         if (want_refl) {
-            ++n_refl;
+            if (by_wave) ++n_refl;
             A.ray_o[refl_idx] = make_float4(pos.x, pos.y, pos.z, refl_contrib);
             A.ray_d[refl_idx] = make_float4(refl_ray.x, refl_ray.y, refl_ray.z, __uint_as_float(hit.prim));
         }
         if (want_refr) {
-            ++n_refr;
+            if (by_wave) ++n_refr;
             A.ray_o[refr_idx] = make_float4(pos.x, pos.y, pos.z, refr_contrib);
             A.ray_d[refr_idx] = make_float4(refr_ray.x, refr_ray.y, refr_ray.z, __uint_as_float(NO_PRIM));
         }
@@ -259,10 +337,15 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
             A.node_kid[node] = make_uint4(refl_idx, refr_idx, __float_as_uint(transmittance), is_hit ? 1u : 0u);
         }
     }
-    const uint32_t s_refl = wave_sum(n_refl), s_refr = wave_sum(n_refr);
-    if (lane_id() == 0) {
-        if (s_refl) atomicAdd(&A.counters[2], (unsigned long long)s_refl);
-        if (s_refr) atomicAdd(&A.counters[3], (unsigned long long)s_refr);
+    if (by_wave) {
+        const uint32_t s_refl = wave_sum(n_refl), s_refr = wave_sum(n_refr);
+        if (lane_id() == 0) {
+            if (s_refl) atomicAdd(&A.counters[2], (unsigned long long)s_refl);
+            if (s_refr) atomicAdd(&A.counters[3], (unsigned long long)s_refr);
+        }
+    } else if (threadIdx.x == 0) {
+        if (block_refl) atomicAdd(&A.counters[2], (unsigned long long)block_refl);
+        if (block_refr) atomicAdd(&A.counters[3], (unsigned long long)block_refr);
     }
     flush_work(A, ctr);
 }
@@ -275,7 +358,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_intersect(FrameArg
 // OCC: 0 = the reference's full closest-hit walk; 1 = stops once "blocked" is certain (same flag);
 // 2 = stops at any hit before the light (rt_options.shadow_mode).
 template <int CULL, class Ctr, int OCC = 0>
-__global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A, uint32_t first_level, uint32_t last_level) {
+__global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(FrameArgs A, uint32_t first_level, uint32_t last_level, uint32_t chunk) {
     extern __shared__ uint2 lds_stack[];
     const DevScene& S = A.scene;
     // A frame whose pools overflowed is run again with larger ones: its shadow rays are wasted
@@ -284,18 +367,84 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_TRACE_WAVES) k_shadow(FrameArgs A
     const uint32_t first = shadow_first(A, first_level);
     uint32_t end = shadow_first(A, last_level + 1);
     end = end < A.shadow_cap ? end : A.shadow_cap;
-    const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
     Ctr ctr;
-    for (uint32_t k = first + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {
-        const uint64_t i = queue + k;
+    auto trace = [&](uint64_t i) {
         const float4 so = A.sray_o[i];
         const float4 sd = A.sray_d[i];
         Hit blocker;
         bool blocked = false;
         if (kd_traverse_closest<CULL, Ctr, OCC>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w),
-                                                            blocker, lds_stack, ctr, so.w))
+                                                blocker, lds_stack, ctr, so.w))
             blocked = blocker.dist <= so.w;
         A.sray_blocked[i] = blocked ? 1u : 0u;
+    };
+    if constexpr ((CULL & 8) != 0) {
+        // staying blocks: one launch for all lights; a wave takes the next of the launch's (light, slot) pairs
+        const uint32_t n = end > first ? end - first : 0u;
+        const uint32_t total = n * S.n_lights;  // (below 2^32: the host caps the queues)
+        uint32_t* next = &A.work_next[RT_MAX_LEVELS + first_level];
+        if (*next >= total) return;  // (the same for all threads of the block)
+        stage_records(S, lds_stack);
+        for (;;) {
+            uint32_t c = 0;
+            if (lane_id() == 0) c = atomicAdd(next, LEAN_TAKE);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= total) break;
+            for (uint32_t part = 0; part < LEAN_TAKE && c + part < total; part += 64u) {
+                const uint32_t w = c + part + lane_id();
+                if (w < total) {
+                    const uint32_t light = w / n;
+                    trace((uint64_t)light * A.shadow_cap + first + (w - light * n));
+                }
+            }
+        }
+    } else if constexpr (RT_SHADOW_REFILL != 0 && (CULL & 4) == 0) {
+        // A wave owns `chunk` consecutive rays of one light's queue at a time, and a lane whose ray
+        // is finished takes the chunk's next one between two rounds of the walk (once enough lanes are idle
+        // to make the fetch worth its instructions): rays differ widely in the number of rounds and
+        // records they take, and a lane that waited for the slowest of its 64 would idle half the time.
+        const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
+        const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+        KdDeep<(CULL & 4) == 0> deep;
+        KdWalk<CULL, Ctr, OCC> w(S, lds_stack, ctr, deep);
+        for (uint64_t c0 = (uint64_t)first + (uint64_t)wave * chunk; c0 < end; c0 += (uint64_t)n_waves * chunk) {
+            uint32_t next = (uint32_t)c0;
+            const uint32_t c_end = c0 + chunk < end ? (uint32_t)c0 + chunk : end;
+            bool have = false;
+            uint32_t mine = 0;
+            float limit = 0.0f;
+            for (;;) {
+                const uint64_t idle = __ballot(!have);
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                if (next < c_end && n_idle >= RT_SHADOW_REFILL) {
+                    const uint32_t idx = next + prefix_count(idle);
+                    next += n_idle;
+                    if (!have && idx < c_end) {
+                        const float4 so = A.sray_o[queue + idx];
+                        const float4 sd = A.sray_d[queue + idx];
+                        w.begin(f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), so.w);
+                        mine = idx;
+                        limit = so.w;
+                        if (w.done) A.sray_blocked[queue + idx] = 0u;  // (misses the scene's box)
+                        else have = true;
+                    }
+                }
+                if (__ballot(have) == 0ull) {
+                    if (next >= c_end) break;
+                    continue;
+                }
+                if (have) {
+                    w.round();
+                    if (w.done) {
+                        A.sray_blocked[queue + mine] = (w.r_hit && w.r.dist <= limit) ? 1u : 0u;
+                        have = false;
+                    }
+                }
+            }
+        }
+    } else {
+        const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
+        for (uint32_t k = first + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) trace(queue + k);
     }
     flush_work<24>(A, ctr);
 }
@@ -600,54 +749,112 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
 // ---------------------------------------------------------------------------------------
 // traversal stack + the per-lane words of the culled leaf walk
 // (the lean kernels keep the whole stack in LDS, the others its newest RT_STACK_RING entries)
-static size_t stack_bytes(const DevScene& S, bool lean_kernel, uint32_t block = RT_BLOCK) {
+static uint32_t g_cus = 256;  // compute units of the device (init_kernels)
+// Which lean kernels run as staying blocks (a fixed set of resident blocks whose waves take rays from the
+// launch's counter, with the scene's bounding records copied into each block's LDS).  Measured on the
+// 7382-sphere scene at 3840x2160: the deeper levels' incoherent rays gain a third; camera rays and shadow
+// rays gain nothing and, with frames in flight, the long-lived blocks keep other frames' kernels off the CUs.
+#ifndef RT_STAY_LEVEL0
+#define RT_STAY_LEVEL0 0
+#endif
+#ifndef RT_STAY_DEEP
+#define RT_STAY_DEEP 1
+#endif
+#ifndef RT_STAY_SHADOW
+#define RT_STAY_SHADOW 0
+#endif
+#ifndef RT_LEVEL0_BLOCK
+#define RT_LEVEL0_BLOCK 256
+#endif
+constexpr int LEAN_I0 = 5 | (RT_STAY_LEVEL0 ? 8 : 0), LEAN_ID = 6 | (RT_STAY_DEEP ? 8 : 0), LEAN_SH = 6 | (RT_STAY_SHADOW ? 8 : 0);
+static const bool g_lean_stays[5] = {RT_STAY_LEVEL0 != 0, RT_STAY_DEEP != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0};
+// Threads per staying block of each lean kernel: RT_LEAN_BLOCKS_PER_CU blocks fill the waves per SIMD the
+// kernel's register use allows (init_kernels).  [0] k_intersect level 0, [1] deeper levels, [2..4] k_shadow by mode.
+static uint32_t g_lean_block[5] = {512, 512, 512, 512, 512};
+static size_t stack_bytes(const DevScene& S, bool lean_kernel, uint32_t block, bool stays) {
     const size_t entries = lean_kernel ? S.stack_depth : RT_STACK_RING;
-    return entries * block * sizeof(uint2) + (size_t)RT_LANE_WORDS * block * sizeof(uint32_t);
+    return entries * block * sizeof(uint2) + (size_t)RT_LANE_WORDS * block * sizeof(uint32_t) +
+           (stays ? (size_t)S.bnd_records * sizeof(float4) : 0);  // (+ the block's copy of the bounding records)
 }
 
 // Threads per block of the trace kernels.  A block keeps its LDS and wave slots until its slowest
 // wave is done, and waves of incoherent rays in trees of small leaves differ widely: those
 // scenes run one wave per block.  Lean scenes (a few huge sphere leaves) do best with two.
-// `grid` counts blocks of RT_BLOCK threads; the launch covers the same number of threads.
-static uint32_t trace_block(const DevScene& S) { return S.lean != 0 ? RT_BLOCK : RT_TRACE_BLOCK_GENERAL; }
+static uint32_t trace_block(const DevScene& S, bool stays, uint32_t which) {
+    if (stays) return g_lean_block[which];
+    if (which == 0) return RT_LEVEL0_BLOCK;  // (camera rays: tiles next to each other take alike, and four waves share a queue append)
+    return S.lean != 0 ? RT_BLOCK : RT_TRACE_BLOCK_GENERAL;
+}
+// `grid` counts blocks of RT_BLOCK threads; a launch of blocks of `tb` threads covers the same
+// number of threads, and a launch of staying blocks never more blocks than stay resident.
+static uint32_t blocks_of(uint32_t grid, uint32_t tb, bool stays) {
+    const uint64_t b = ((uint64_t)grid * RT_BLOCK + tb - 1) / tb;
+    return (uint32_t)(stays ? (b < (uint64_t)g_cus * RT_LEAN_BLOCKS_PER_CU ? b : (uint64_t)g_cus * RT_LEAN_BLOCKS_PER_CU) : b);
+}
 
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
 hipError_t init_kernels() {
     const int max_lds = 160 * 1024;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            g_cus = (uint32_t)cus;
+    }
     const void* fns[] = {(const void*)k_intersect<true, 0, WorkCounters>, (const void*)k_intersect<true, 1, WorkCounters>,
                          (const void*)k_intersect<true, 0, NoCounters>, (const void*)k_intersect<true, 1, NoCounters>,
                          (const void*)k_intersect<false, 0, WorkCounters>, (const void*)k_intersect<false, 2, WorkCounters>,
                          (const void*)k_intersect<false, 0, NoCounters>, (const void*)k_intersect<false, 2, NoCounters>,
                          (const void*)k_shadow<0, WorkCounters>, (const void*)k_shadow<2, WorkCounters>,
                          (const void*)k_shadow<0, NoCounters>, (const void*)k_shadow<2, NoCounters>,
-                         (const void*)k_intersect<true, 5, NoCounters>, (const void*)k_intersect<false, 6, NoCounters>,
-                         (const void*)k_shadow<6, NoCounters>,
-                         (const void*)k_shadow<2, NoCounters, 1>, (const void*)k_shadow<6, NoCounters, 1>,
-                         (const void*)k_shadow<2, NoCounters, 2>, (const void*)k_shadow<6, NoCounters, 2>,
+                         (const void*)k_intersect<true, LEAN_I0, NoCounters>, (const void*)k_intersect<false, LEAN_ID, NoCounters>,
+                         (const void*)k_shadow<LEAN_SH, NoCounters>,
+                         (const void*)k_shadow<2, NoCounters, 1>, (const void*)k_shadow<LEAN_SH, NoCounters, 1>,
+                         (const void*)k_shadow<2, NoCounters, 2>, (const void*)k_shadow<LEAN_SH, NoCounters, 2>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
     for (const void* f : fns) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, f);  // (the kernel's own static LDS counts against the same 160 KiB)
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - (int)fa.sharedSizeBytes);
+        if (e != hipSuccess) return e;
+    }
+    // lean kernels: waves per SIMD by their vector registers (512 per lane and SIMD, in steps of 8), and the
+    // block size at which RT_LEAN_BLOCKS_PER_CU blocks make exactly that many
+    const void* lean_fns[5] = {(const void*)k_intersect<true, LEAN_I0, NoCounters>, (const void*)k_intersect<false, LEAN_ID, NoCounters>,
+                               (const void*)k_shadow<LEAN_SH, NoCounters>, (const void*)k_shadow<LEAN_SH, NoCounters, 1>,
+                               (const void*)k_shadow<LEAN_SH, NoCounters, 2>};
+    for (int k = 0; k < 5; ++k) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, lean_fns[k]);
+        if (e != hipSuccess) return e;
+        const uint32_t regs = ((uint32_t)(fa.numRegs > 0 ? fa.numRegs : 128) + 7u) & ~7u;
+        uint32_t waves = 512u / regs;
+        waves = waves < 1u ? 1u : (waves > 8u ? 8u : waves);
+        uint32_t threads = waves * 4u * 64u / RT_LEAN_BLOCKS_PER_CU;
+        if (threads > RT_LEAN_BLOCK) threads = RT_LEAN_BLOCK;
+        g_lean_block[k] = threads < 64u ? 64u : threads;
     }
     return hipSuccess;
 }
 
 // `work` selects the instrumented kernels, `cull` the culled walk of big leaves.
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
-    const uint32_t tb = trace_block(A.scene);
-    const dim3 g(grid * (RT_BLOCK / tb)), b(tb);
     const bool lean = A.scene.lean != 0;
-    const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb);
+    const uint32_t which = level == 0 ? 0u : 1u;
+    const bool stays = !work && cull && lean && g_lean_stays[which];
+    const uint32_t tb = trace_block(A.scene, stays, which);
+    const dim3 g(blocks_of(grid, tb, stays)), b(tb);
+    const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays);
     if (level == 0) {  // camera rays start outside the scene: the line test alone
         if (work && cull) hipLaunchKernelGGL((k_intersect<true, 1, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<true, 0, WorkCounters>), g, b, lds, st, A, level);
-        else if (cull && lean) hipLaunchKernelGGL((k_intersect<true, 5, NoCounters>), g, b, lds, st, A, level);
+        else if (cull && lean) hipLaunchKernelGGL((k_intersect<true, LEAN_I0, NoCounters>), g, b, lds, st, A, level);
         else if (cull) hipLaunchKernelGGL((k_intersect<true, 1, NoCounters>), g, b, lds, st, A, level);
         else hipLaunchKernelGGL((k_intersect<true, 0, NoCounters>), g, b, lds, st, A, level);
     } else {
         if (work && cull) hipLaunchKernelGGL((k_intersect<false, 2, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<false, 0, WorkCounters>), g, b, lds, st, A, level);
-        else if (cull && lean) hipLaunchKernelGGL((k_intersect<false, 6, NoCounters>), g, b, lds, st, A, level);
+        else if (cull && lean) hipLaunchKernelGGL((k_intersect<false, LEAN_ID, NoCounters>), g, b, lds, st, A, level);
         else if (cull) hipLaunchKernelGGL((k_intersect<false, 2, NoCounters>), g, b, lds, st, A, level);
         else hipLaunchKernelGGL((k_intersect<false, 0, NoCounters>), g, b, lds, st, A, level);
     }
@@ -656,25 +863,38 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 
 hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, uint32_t grid,
                          hipStream_t st) {
-    const uint32_t tb = trace_block(A.scene);
-    const size_t lds = stack_bytes(A.scene, !work && cull && A.scene.lean != 0, tb);
-    const dim3 g(grid * (RT_BLOCK / tb), A.scene.n_lights), b(tb);
+    const bool lean_kernel = !work && cull && A.scene.lean != 0;
+    const uint32_t which = 2u + (A.shadow_mode <= 2u ? A.shadow_mode : 0u);
+    const bool stays = lean_kernel && g_lean_stays[which];
+    const uint32_t tb = trace_block(A.scene, stays, which);
+    const size_t lds = stack_bytes(A.scene, lean_kernel, tb, stays);
+    // (a launch of staying blocks covers all lights with one set of blocks)
+    // Rays a wave owns at a time (k_shadow): as many as leave every SIMD its four waves, at most RT_SHADOW_CHUNK.
+    uint32_t chunk = 64u;
+    if (RT_SHADOW_REFILL != 0 && !lean_kernel && A.scene.refill != 0u) {
+        // (eight times as many waves as the device holds at once, or the last ones run on a half-empty device)
+        const uint64_t rays = (uint64_t)grid * RT_BLOCK * A.scene.n_lights;
+        const uint64_t fair = rays / ((uint64_t)g_cus * 16u * 8u) / 64u * 64u;
+        chunk = (uint32_t)(fair < 64u ? 64u : (fair > RT_SHADOW_CHUNK ? RT_SHADOW_CHUNK : fair));
+    }
+    const uint32_t grid_c = (uint32_t)(((uint64_t)grid * 64u + chunk - 1u) / chunk);
+    const dim3 g(stays ? blocks_of(grid * A.scene.n_lights, tb, true) : blocks_of(grid_c, tb, false), stays ? 1u : A.scene.n_lights), b(tb);
     // shadow rays start on a surface, among the primitives, at every level: the behind-origin test pays
     const int mode = cull ? 2 : 0;
     const bool lean = A.scene.lean != 0;
     if (work) {
-        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level);
-        else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, first_level, last_level);
+        if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+        else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);
     } else if (mode == 2 && A.shadow_mode == 1) {
-        if (lean) hipLaunchKernelGGL((k_shadow<6, NoCounters, 1>), g, b, lds, st, A, first_level, last_level);
-        else hipLaunchKernelGGL((k_shadow<2, NoCounters, 1>), g, b, lds, st, A, first_level, last_level);
+        if (lean) hipLaunchKernelGGL((k_shadow<LEAN_SH, NoCounters, 1>), g, b, lds, st, A, first_level, last_level, chunk);
+        else hipLaunchKernelGGL((k_shadow<2, NoCounters, 1>), g, b, lds, st, A, first_level, last_level, chunk);
     } else if (mode == 2 && A.shadow_mode == 2) {
-        if (lean) hipLaunchKernelGGL((k_shadow<6, NoCounters, 2>), g, b, lds, st, A, first_level, last_level);
-        else hipLaunchKernelGGL((k_shadow<2, NoCounters, 2>), g, b, lds, st, A, first_level, last_level);
+        if (lean) hipLaunchKernelGGL((k_shadow<LEAN_SH, NoCounters, 2>), g, b, lds, st, A, first_level, last_level, chunk);
+        else hipLaunchKernelGGL((k_shadow<2, NoCounters, 2>), g, b, lds, st, A, first_level, last_level, chunk);
     } else {
-        if (mode == 2 && lean) hipLaunchKernelGGL((k_shadow<6, NoCounters>), g, b, lds, st, A, first_level, last_level);
-        else if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, first_level, last_level);
-        else hipLaunchKernelGGL((k_shadow<0, NoCounters>), g, b, lds, st, A, first_level, last_level);
+        if (mode == 2 && lean) hipLaunchKernelGGL((k_shadow<LEAN_SH, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+        else if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+        else hipLaunchKernelGGL((k_shadow<0, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
     }
     return hipGetLastError();
 }
@@ -716,8 +936,8 @@ hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, cons
                                   const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist,
                                   float* out_normal, hipStream_t st) {
     const dim3 g((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), b(RT_BLOCK);
-    if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
-    else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     return hipGetLastError();
 }
 

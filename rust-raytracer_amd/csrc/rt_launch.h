@@ -12,6 +12,14 @@
 #endif
 #define RT_MAX_LEVELS 64  // max_depth + 2 must fit
 #define RT_LANE_WORDS 16
+// The lean trace kernels run as a few big blocks that stay: each copies the bounding records into
+// its LDS once, then its waves take 64 rays at a time from a counter until the launch's rays are
+// used up (no wave waits for a slower one, whatever the block's size).  640 threads = 10 waves; two
+// such blocks per CU hold 2 x (10 waves' stacks and lane words + the records) in the 160 KiB of LDS
+// and give every SIMD 5 waves.
+#define RT_LEAN_BLOCK 640
+#define RT_LEAN_BLOCKS_PER_CU 2
+#define RT_LEAN_RECORD_BYTES 24576 // most bounding-record bytes a lean kernel's block copies into LDS
 // Traversal stack of the general kernels: the newest RT_STACK_RING entries of a lane sit in LDS,
 // older ones in the lane's private memory, so that a deep tree does not cost occupancy (every
 // 8 levels of an all-LDS stack take 16 KiB per block of 256 lanes); RT_STACK_DEEP entries there.
@@ -50,7 +58,11 @@ struct DevScene {
     const float4* lights;      // 2 per light: {position, 0} {color, 0}
     uint32_t n_lights;
     uint32_t stack_depth;      // depth of the tree (>= 1): the most entries a lane's traversal stack can hold
-    uint32_t lean;             // 1: no cones and no polygon run with bounding records anywhere in the scene
+    uint32_t lean;             // 1: no cones and no polygon run with bounding records anywhere in the scene, and
+                               // few enough bounding records for a copy in every block's LDS
+    uint32_t bnd_records;      // float4 records in bnd
+    uint32_t refill;           // 1: shadow waves own a run of rays and their lanes take the next ray as they finish
+                               // (trees of small leaves, where rays differ most in the number of leaves they visit)
     float bg[3];
     float root_min[3], root_max[3];  // the root node's box
 };
@@ -88,6 +100,7 @@ struct FrameArgs {
     uint32_t* shadow_count; // [RT_MAX_LEVELS] lit hits of each level (each takes one slot in every queue);
                             // a level's slots follow those of the levels before it
     uint32_t* overflow;
+    uint32_t* work_next;    // [2 * RT_MAX_LEVELS] next ray of a lean launch: k_intersect of level l -> [l], k_shadow from level f -> [RT_MAX_LEVELS + f]
     unsigned long long* counters;  // [40]: -, -, reflect, refract, 16 work counters of k_intersect / k_light, 4 unused, 16 of k_shadow
     // outputs (either may be null)
     float* out_f32;

@@ -344,6 +344,37 @@ RT_DEV bool bound_may_hit(float4 rec, F3 src, F3 n) {
 // The ray's direction at unit length for the bounding tests (a = |ray|^2, finite and normal).
 RT_DEV F3 unit_ray(F3 ray, float a) { return mul(ray, 1.0f / sqrtf(a)); }
 
+// Bounding records in LDS (the lean kernels copy the scene's whole record array there when a block
+// starts).  Why: lanes of incoherent rays each read their own 128-byte group, 64 different cache
+// lines per load instruction, and the vector L1 looks up one line per cycle -- eight instructions
+// per step make that the walk's bottleneck (measured: tools/micro/gather_rate.hip, 16 B per cycle
+// and CU).  The LDS serves 16 lanes per cycle if they ask for different 16-byte slots of its
+// 256-byte row; a group is 128-byte aligned, so lanes reading "record k of my group" together
+// would meet in two slots.  Each lane therefore reads its group's records in an order rotated by
+// its lane number (slot (k + lane) mod 8 at step k), which spreads 16 lanes over all 16 slots
+// (110 B per cycle and CU measured), and rotates the resulting mask back.
+typedef __attribute__((address_space(3))) const f32x4* lds_cf4_ptr;
+RT_DEV float4 ld_lds(lds_cf4_ptr p, uint32_t i) {
+    const f32x4 v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool BEHIND, class Ctr>
+RT_DEV uint32_t expand8_lds(lds_cf4_ptr recs, uint32_t first, uint32_t valid, uint32_t rot, F3 src, F3 n, Ctr& ctr) {
+    float4 r[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) r[k] = ld_lds(recs, first + ((k + rot) & 7u));
+    uint32_t ms = 0;  // bit k: the record in slot (k + rot) mod 8
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ms |= bound_may_hit<BEHIND>(r[k], src, n) ? (1u << k) : 0u;
+    ctr.bound_tests(8);
+    if constexpr (Ctr::kEnabled) {
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true)))
+            ctr.lane_slots(8 * 64);
+    }
+    const uint32_t m = ((ms << rot) | (ms >> (8u - rot))) & 0xffu;
+    return valid >= 8u ? m : (m & ((1u << valid) - 1u));
+}
+
 // Live mask of the records base[0..8), of which the first `valid` exist (the array is padded
 // so that all 8 loads are in bounds).
 template <bool BEHIND, class Ctr>
@@ -410,12 +441,19 @@ RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, fl
 // A lane's traversal stack.  RING false: entry k at lds[k * stride].  RING true: entries
 // [lo, sp) in the LDS slots k % RT_STACK_RING, entries [0, lo) in private memory; a push into a
 // full ring moves the oldest entry out first, a pop from an empty ring reads the entry back.
+// Private memory for the oldest entries of a deep tree's stack (indexed by a variable, so it lives in
+// scratch; kept apart from the walk's other state, which must stay in registers).
+template <bool RING>
+struct KdDeep {
+    uint2 e[RING ? RT_STACK_DEEP : 1];
+};
+
 template <bool RING>
 struct KdStack {
     uint2* lds;
     uint32_t stride, sp, lo;
-    uint2 deep[RING ? RT_STACK_DEEP : 1];
-    RT_DEV void init(uint2* lane_base, uint32_t lane_stride) { lds = lane_base; stride = lane_stride; sp = 0; lo = 0; }
+    uint2* deep;  // RING: the caller's RT_STACK_DEEP entries of private memory (KdDeep), for what the ring pushes out
+    RT_DEV void init(uint2* lane_base, uint32_t lane_stride, uint2* deep_store) { lds = lane_base; stride = lane_stride; sp = 0; lo = 0; deep = deep_store; }
     RT_DEV bool empty() const { return sp == 0; }
     RT_DEV void push(uint2 v) {
         if constexpr (RING) {
@@ -469,17 +507,17 @@ struct KdStack {
 template <bool RING, bool ANY>
 struct Occluder {
     static constexpr bool kOn = true;
-    const KdStack<RING>* st;
     F3 src, ray;
     float limit;    // -inf: never decides
     float checked;  // a t that did not pass the pending entries (t only shrinks: not tried again)
     bool hit;
-    RT_DEV void init(const KdStack<RING>* s, F3 o, F3 d, float lim) { st = s; src = o; ray = d; limit = lim; checked = -1.0f; hit = false; }
-    RT_DEV bool decided(const LeafBest& lb) {
+    RT_DEV void init(F3 o, F3 d, float lim) { src = o; ray = d; limit = lim; checked = -1.0f; hit = false; }
+    // (st: the walk's pending entries)
+    RT_DEV bool decided(const KdStack<RING>& st, const LeafBest& lb) {
         if (hit) return true;
         if (!lb.have || !(lb.t <= limit) || lb.t == checked) return false;
-        for (uint32_t k = ANY ? 0u : st->sp; k-- > 0u;) {
-            const uint2 ent = st->get(k);
+        for (uint32_t k = ANY ? 0u : st.sp; k-- > 0u;) {
+            const uint2 ent = st.get(k);
             const uint32_t axis = ent.x >> 30;
             const float plane = __uint_as_float(ent.y);
             const float endpoint = comp(src, axis) + comp(ray, axis) * lb.t;
@@ -495,18 +533,22 @@ struct Occluder {
 };
 struct NoOccluder {
     static constexpr bool kOn = false;
-    RT_DEV bool decided(const LeafBest&) { return false; }
+    template <class St>
+    RT_DEV bool decided(const St&, const LeafBest&) { return false; }
 };
 
 // KIND 1: the run holds polygons, KIND 2: cones with equal radii; each is bounded by the sphere
 // polygon_bound / cylinder_bound (leaf_cluster.cpp) derives for it, and the records and their
 // test are the same as for spheres (KIND 0).
-template <int KIND, bool BEHIND, class Ctr, class Occ>
+// LREC: the bounding records are read from `lrec`, the block's LDS copy of S.bnd (lean kernels).
+template <int KIND, bool BEHIND, bool LREC, class Ctr, class Occ, class St>
 RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, F3 un, float a,
-                          float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride, Occ& occ) {
-    const float4 hf = S.bnd[header];
+                          float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride, Occ& occ,
+                          const St& st, lds_cf4_ptr lrec) {
+    const float4 hf = LREC ? ld_lds(lrec, header) : S.bnd[header];
     ctr.bound_tests(1);
-    if (!bound_may_hit<BEHIND>(S.bnd[header + 1u], src, un)) return;  // misses the whole run
+    if (!bound_may_hit<BEHIND>(LREC ? ld_lds(lrec, header + 1u) : S.bnd[header + 1u], src, un)) return;  // misses the whole run
+    const uint32_t rot = threadIdx.x & 7u;
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
                    off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w) & 7u;
     const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
@@ -529,7 +571,7 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             else if constexpr (KIND == 2) cylinders8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
             else cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
             if constexpr (Occ::kOn) {
-                if (occ.decided(lb)) {  // (a shadow ray that is known to be blocked)
+                if (occ.decided(st, lb)) {  // (a shadow ray that is known to be blocked)
                     qn = 0u;
                     return;
                 }
@@ -575,7 +617,8 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             }
             g = g * 8u + k;  // record g*8+k of level L = group of that index one level down
             L -= 1u;
-            m = expand8<BEHIND>(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, un, ctr);
+            if constexpr (LREC) m = expand8_lds<BEHIND>(lrec, level_off(L) + g * 8u, level_n(L) - g * 8u, rot, src, un, ctr);
+            else m = expand8<BEHIND>(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, un, ctr);
         }
     }
     drain();
@@ -636,53 +679,53 @@ __device__ unsigned long long g_phase[8];
 #define RT_PHASE_END() do {} while (0)
 #endif
 
-// CULL: 0 = every entry of every visited leaf, 1 = big runs skip groups the ray's line misses,
-// 2 = also groups behind the ray's origin (worth its cost for rays that start inside the
-// scene); + 4 = the scene has neither cones nor polygon runs with bounding records, and the
-// kernel carries no code for them (kilobytes less for the instruction cache, which the
-// intersect and shadow kernels of a frame share).
-// OCC != 0 (shadow rays; needs near == 0): `limit` is the distance that matters, and the walk stops
-// as soon as the answer "a hit at most that far" is certain (1, Occluder) or as soon as any such
-// hit is found (2, not the reference's answer in every case); out.dist is then some distance <=
-// limit, not the nearest.
-template <int CULL, class Ctr, int OCC = 0>
-RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
-                                uint2* stack, Ctr& ctr, float limit = 0.0f) {
-    RayInv ri;
-    ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
-    {
-        const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
-        ri.quick = (ax == 0.0f || (ax >= 1e-30f && ax <= 1e30f)) && (ay == 0.0f || (ay >= 1e-30f && ay <= 1e30f)) &&
-                   (az == 0.0f || (az >= 1e-30f && az <= 1e30f));
+// The lean kernels' copy of the scene's bounding records in LDS, made by all threads of a block when
+// it starts (behind the traversal stack and the lane words; a barrier follows).
+RT_DEV void stage_records(const DevScene& S, uint2* stack) {
+    f32x4* dst = (f32x4*)((uint32_t*)(stack + S.stack_depth * blockDim.x) + (uint32_t)RT_LANE_WORDS * blockDim.x);
+    for (uint32_t i = threadIdx.x; i < S.bnd_records; i += blockDim.x) {
+        const float4 v = S.bnd[i];
+        f32x4 w;
+        w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+        dst[i] = w;
     }
-    const float a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
-    const uint32_t stride = blockDim.x;
-    constexpr bool LEAN = (CULL & 4) != 0;
-    KdStack<!LEAN> st;
-    st.init(stack + threadIdx.x, stride);
-    // RT_LANE_WORDS per lane behind the stack's LDS entries, same stride
-    uint32_t* lane_words = (uint32_t*)(stack + (LEAN ? S.stack_depth : (uint32_t)RT_STACK_RING) * stride) + threadIdx.x;
-    // The bounding-record tests assume that their intermediate values stay finite and normal,
-    // and the one that looks behind the origin that hits before the origin do not count.
-    constexpr int MODE = CULL & 3;
-    const bool tame = a >= 1e-30f && a < 1e16f && dot(src, src) < 1e16f && (MODE != 2 || near >= 0.0f);
-    F3 un = ray;
-    if constexpr (MODE != 0) un = unit_ray(ray, a);
-    constexpr bool OCCL = OCC != 0;
-    typename std::conditional<OCCL, Occluder<!LEAN, OCC == 2>, NoOccluder>::type occ;
-    if constexpr (OCCL) occ.init(&st, src, ray, (tame && near == 0.0f && limit < 1e30f) ? limit : -INFINITY);
-    constexpr int BND = LEAN ? 0 : MODE;  // (a lean scene has no cones and next to no polygons)
-    const bool ok_cone = tame && near >= 0.0f;
-    uint32_t cur = 0;
-    bool done = false;
-    bool r_hit = false;
-    Hit r;
-    r.dist = 0.0f; r.prim = NO_PRIM; r.n = f3(0.0f, 0.0f, 0.0f);
+    __syncthreads();
+}
 
-    RT_PHASE_T0();
-    // A node's record holds its children's boxes: one fetch per interior node on the path, both
-    // children's box tests from it, and no fetch at all for a child whose box the ray misses.
-    auto box_hit = [&](F3 bmin, F3 bmax) -> bool {
+// One ray's walk, in steps: begin() takes the ray and tests the root's box; each round() goes on to
+// the next leaf whose box the ray passes, finishes that leaf and unwinds; `done` ends it, with the
+// result in r_hit / r.  (The kernels' lanes take their next ray between rounds.)
+template <int CULL, class Ctr, int OCC = 0>
+struct KdWalk {
+    static constexpr bool LEAN = (CULL & 4) != 0;
+    static constexpr int MODE = CULL & 3;
+    static constexpr bool OCCL = OCC != 0;
+    static constexpr int BND = LEAN ? 0 : MODE;  // (a lean scene has no cones and next to no polygons)
+    const DevScene& S;
+    Ctr& ctr;
+    F3 src, ray, un;
+    float near, a;
+    uint32_t ignore, stride, cur;
+    RayInv ri;
+    KdStack<!LEAN> st;
+    uint32_t* lane_words;
+    lds_cf4_ptr lrec;
+    bool tame, ok_cone, done, r_hit;
+    Hit r;
+    typename std::conditional<OCCL, Occluder<!LEAN, OCC == 2>, NoOccluder>::type occ;
+
+    RT_DEV KdWalk(const DevScene& scene, uint2* stack, Ctr& c, KdDeep<!LEAN>& deep) : S(scene), ctr(c) {
+        stride = blockDim.x;
+        st.init(stack + threadIdx.x, stride, deep.e);
+        // RT_LANE_WORDS per lane behind the stack's LDS entries, same stride; behind them, in the lean
+        // kernels, the block's copy of the bounding records (stage_records)
+        lane_words = (uint32_t*)(stack + (LEAN ? S.stack_depth : (uint32_t)RT_STACK_RING) * stride) + threadIdx.x;
+        lrec = (lds_cf4_ptr)(lane_words - threadIdx.x + (uint32_t)RT_LANE_WORDS * stride);
+        done = true;
+        r_hit = false;
+    }
+
+    RT_DEV bool box_hit(F3 bmin, F3 bmax) const {
 #if RT_FAST
         return aabb_slab_test(bmin, bmax, src, ray, near, ri);
 #else
@@ -691,11 +734,38 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
         if (!ri.quick || !aabb_quick(bmin, bmax, src, ray, near, ri.inv, in_box)) in_box = aabb_slab_test(bmin, bmax, src, ray, near, ri);
         return in_box;
 #endif
-    };
-    ctr.node_visits(1);
-    if (!box_hit(f3(S.root_min[0], S.root_min[1], S.root_min[2]), f3(S.root_max[0], S.root_max[1], S.root_max[2]))) done = true;  // :276-279
-    while (!done) {
-        // ---- walk until this lane stands on a leaf whose box it hits, or is finished
+    }
+
+    RT_DEV void begin(F3 src_, F3 ray_, float near_, uint32_t ignore_, float limit) {
+        src = src_; ray = ray_; near = near_; ignore = ignore_;
+        ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+        {
+            const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
+            ri.quick = (ax == 0.0f || (ax >= 1e-30f && ax <= 1e30f)) && (ay == 0.0f || (ay >= 1e-30f && ay <= 1e30f)) &&
+                       (az == 0.0f || (az >= 1e-30f && az <= 1e30f));
+        }
+        a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
+        st.sp = 0;
+        st.lo = 0;
+        // The bounding-record tests assume that their intermediate values stay finite and normal,
+        // and the one that looks behind the origin that hits before the origin do not count.
+        tame = a >= 1e-30f && a < 1e16f && dot(src, src) < 1e16f && (MODE != 2 || near >= 0.0f);
+        un = ray;
+        if constexpr (MODE != 0) un = unit_ray(ray, a);
+        if constexpr (OCCL) occ.init(src, ray, (tame && near == 0.0f && limit < 1e30f) ? limit : -INFINITY);
+        ok_cone = tame && near >= 0.0f;
+        cur = 0;
+        r_hit = false;
+        r.dist = 0.0f; r.prim = NO_PRIM; r.n = f3(0.0f, 0.0f, 0.0f);
+        ctr.node_visits(1);
+        // A node's record holds its children's boxes: one fetch per interior node on the path, both
+        // children's box tests from it, and no fetch at all for a child whose box the ray misses.
+        done = !box_hit(f3(S.root_min[0], S.root_min[1], S.root_min[2]), f3(S.root_max[0], S.root_max[1], S.root_max[2]));  // :276-279
+    }
+
+    RT_DEV void round() {
+        RT_PHASE_T0();
+            // ---- walk until this lane stands on a leaf whose box it hits, or is finished
         bool at_leaf = false;
         uint32_t leaf_w = 0xffffffffu;  // a leaf's first word: header of its cylinder run's records, or none
         uint4 q2 = make_uint4(0, 0, 0, 0), q3 = make_uint4(0, 0, 0, 0);
@@ -741,19 +811,19 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
             }
             if constexpr (MODE != 0) {
                 if (q2.y >= CULL_MIN_SPHERES && tame) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_run_lane<0, MODE == 2>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ);
+                    leaf_run_lane<0, MODE == 2, (CULL & 8) != 0>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec);
                     q2.y = 0u;
                 }
                 RT_PHASE(1);  // sphere hierarchy
                 if constexpr (!LEAN) {
-                    if (q3.w != 0xffffffffu && tame && !occ.decided(lb)) {  // polygon run with bounding records
-                        leaf_run_lane<1, MODE == 2>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ);
+                    if (q3.w != 0xffffffffu && tame && !occ.decided(st, lb)) {  // polygon run with bounding records
+                        leaf_run_lane<1, MODE == 2, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec);
                         q3.y = 0u;
                     }
                     RT_PHASE(2);  // polygon hierarchy
-                    if (cyl_n != 0u && tame && near >= 0.0f && !occ.decided(lb)) {  // cylinder run with bounding records
-                        leaf_run_lane<2, MODE == 2>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, un, a, near, ignore, lb, ctr,
-                                                    lane_words, stride, occ);
+                    if (cyl_n != 0u && tame && near >= 0.0f && !occ.decided(st, lb)) {  // cylinder run with bounding records
+                        leaf_run_lane<2, MODE == 2, false>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, un, a, near, ignore, lb, ctr,
+                                                           lane_words, stride, occ, st, lrec);
                         cyl_n = 0u;
                     }
                     RT_PHASE(3);  // cylinder hierarchy
@@ -764,7 +834,7 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                 q2.w += cyl_n;
             }
             if constexpr (OCCL) {
-                if (occ.decided(lb)) q2.y = q2.w = q3.y = 0u;  // blocked for certain: nothing left to look at
+                if (occ.decided(st, lb)) q2.y = q2.w = q3.y = 0u;  // blocked for certain: nothing left to look at
             }
             // What is left (short runs, cones, rays the bounding test cannot take): entry by entry.
             // Long lists are walked by all lanes standing on the same leaf together, index
@@ -812,15 +882,34 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
                 }
             }
             bool stop_here = false;
-            if constexpr (OCCL) stop_here = occ.decided(lb);
+            if constexpr (OCCL) stop_here = occ.decided(st, lb);
             if (stop_here) done = true;
             else if (!unwind(st, src, ray, r_hit, r.dist, cur, ctr)) done = true;
             RT_PHASE(5);  // result + unwind
         }
+        RT_PHASE_END();
     }
-    RT_PHASE_END();
-    out = r;
-    return r_hit;
+};
+
+// CULL: 0 = every entry of every visited leaf, 1 = big runs skip groups the ray's line misses,
+// 2 = also groups behind the ray's origin (worth its cost for rays that start inside the
+// scene); + 4 = the scene has neither cones nor polygon runs with bounding records, and the
+// kernel carries no code for them (kilobytes less for the instruction cache, which the
+// intersect and shadow kernels of a frame share); + 8, lean kernels only: the bounding records are
+// read from the block's LDS copy.
+// OCC != 0 (shadow rays; needs near == 0): `limit` is the distance that matters, and the walk stops
+// as soon as the answer "a hit at most that far" is certain (1, Occluder) or as soon as any such
+// hit is found (2, not the reference's answer in every case); out.dist is then some distance <=
+// limit, not the nearest.
+template <int CULL, class Ctr, int OCC = 0>
+RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
+                                uint2* stack, Ctr& ctr, float limit = 0.0f) {
+    KdDeep<(CULL & 4) == 0> deep;
+    KdWalk<CULL, Ctr, OCC> w(S, stack, ctr, deep);
+    w.begin(src, ray, near, ignore, limit);
+    while (!w.done) w.round();
+    out = w.r;
+    return w.r_hit;
 }
 
 }  // namespace RT_NS
