@@ -304,14 +304,8 @@ def main():
     sh_bytes = sh_rays * (32 + 4) + sum(work_shadow.get(k, 0.0) * c for k, c in BYTES.items())
     sh_s = kernel_ms["ms_shadow"] * 1e-3 if kernel_ms["ms_shadow"] > 0 else float("nan")
     sh_traffic = traffic.get("k_shadow", {}).get("hbm_bytes_per_launch") if traffic else None
-    src_commit = None
-    if traffic_file:
-        try:
-            import subprocess
-            src_commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", traffic_file], capture_output=True,
-                                        text=True, timeout=10).stdout.strip() or None
-        except Exception:
-            src_commit = None
+    # (the commit whose build the counters were taken on: stamped into the file by tools/keep_profile.py)
+    src_commit = traffic.get("commit") if traffic else None
     frame_s = kernel_ms["ms_frame"] * 1e-3
 
     out = {
