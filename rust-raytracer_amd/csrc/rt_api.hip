@@ -602,6 +602,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.bnd_records = (uint32_t)(bnd.size() / 4);
     d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8 && d.stack_depth <= RT_STACK_RING &&
               bnd.size() * sizeof(float) <= RT_LEAN_RECORD_BYTES) ? 1u : 0u;
+    d.n_nodes = (uint32_t)sc->tree.nodes.size();
+    d.nodes_lds = (d.lean == 0u && (size_t)d.n_nodes * 64u <= RT_NODE_LDS_BYTES) ? 1u : 0u;
     // Measured at 3840x2160 (k_shadow, ms, lanes waiting for their wave / lanes taking the next ray): rings 4
     // (largest leaf 212) 23.1 / 18.4; lathe 96 at 1920x1080 (273) 2.41 / 2.34; mount 8 (45685) 6.4 / 8.0;
     // balls 4 (lean) 2.79 / 3.44.

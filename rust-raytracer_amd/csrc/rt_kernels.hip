@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
     if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = next_base;
     if constexpr ((CULL & 8) != 0) {
         if (A.work_next[level] >= count) return;  // (a block that comes when the level is used up; the same for all its threads)
-        stage_records(S, lds_stack);
+        stage_scene<CULL>(S, lds_stack);
     }
     const uint32_t n_lights = S.n_lights;
     const uint32_t sh_base = shadow_first(A, level);
@@ -368,6 +368,9 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
     uint32_t end = shadow_first(A, last_level + 1);
     end = end < A.shadow_cap ? end : A.shadow_cap;
     Ctr ctr;
+    constexpr bool LEAN = (CULL & 4) != 0, STAYS = (CULL & 8) != 0;
+    const uint32_t n = end > first ? end - first : 0u;  // slots of one light's queue in this launch
+    // Lean kernels: 64 rays at a time, every lane its own walk from start to end.
     auto trace = [&](uint64_t i) {
         const float4 so = A.sray_o[i];
         const float4 sd = A.sray_d[i];
@@ -378,70 +381,82 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
             blocked = blocker.dist <= so.w;
         A.sray_blocked[i] = blocked ? 1u : 0u;
     };
-    if constexpr ((CULL & 8) != 0) {
+    // Position w of the launch's rays (light after light, `n` slots each) in the queue arrays.
+    auto slot_of = [&](uint32_t w) -> uint64_t {
+        const uint32_t light = w / n;
+        return (uint64_t)light * A.shadow_cap + first + (w - light * n);
+    };
+    // The other kernels: a wave owns a run of consecutive rays at a time, and a lane whose ray is
+    // finished takes the run's next one between two rounds of the walk (once RT_SHADOW_REFILL lanes are
+    // idle, which makes the fetch worth its instructions): in trees of small leaves rays differ widely
+    // in the number of rounds they take, and a lane that waited for the slowest of its 64 would idle
+    // half the time.  (A run of 64 rays is a wave that traces 64 rays and is done.)
+    auto trace_run = [&](KdWalk<CULL, Ctr, OCC>& w, uint32_t c0, uint32_t c_end, uint64_t queue, bool linear) {
+        uint32_t next = c0;
+        bool have = false;
+        uint64_t mine = 0;
+        float limit = 0.0f;
+        for (;;) {
+            const uint64_t idle = __ballot(!have);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (next < c_end && n_idle >= RT_SHADOW_REFILL) {
+                const uint32_t idx = next + prefix_count(idle);
+                next += n_idle;
+                if (!have && idx < c_end) {
+                    const uint64_t at = linear ? slot_of(idx) : queue + idx;
+                    const float4 so = A.sray_o[at];
+                    const float4 sd = A.sray_d[at];
+                    w.begin(f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), so.w);
+                    mine = at;
+                    limit = so.w;
+                    if (w.done) A.sray_blocked[at] = 0u;  // (misses the scene's box)
+                    else have = true;
+                }
+            }
+            if (__ballot(have) == 0ull) {
+                if (next >= c_end) break;
+                continue;
+            }
+            if (have) {
+                w.round();
+                if (w.done) {
+                    A.sray_blocked[mine] = (w.r_hit && w.r.dist <= limit) ? 1u : 0u;
+                    have = false;
+                }
+            }
+        }
+    };
+    if constexpr (STAYS) {
         // staying blocks: one launch for all lights; a wave takes the next of the launch's (light, slot) pairs
-        const uint32_t n = end > first ? end - first : 0u;
         const uint32_t total = n * S.n_lights;  // (below 2^32: the host caps the queues)
         uint32_t* next = &A.work_next[RT_MAX_LEVELS + first_level];
         if (*next >= total) return;  // (the same for all threads of the block)
-        stage_records(S, lds_stack);
+        stage_scene<CULL>(S, lds_stack);
+        KdDeep<!LEAN> deep;
+        KdWalk<CULL, Ctr, OCC> w(S, lds_stack, ctr, deep);
         for (;;) {
             uint32_t c = 0;
             if (lane_id() == 0) c = atomicAdd(next, LEAN_TAKE);
             c = __builtin_amdgcn_readfirstlane(c);
             if (c >= total) break;
-            for (uint32_t part = 0; part < LEAN_TAKE && c + part < total; part += 64u) {
-                const uint32_t w = c + part + lane_id();
-                if (w < total) {
-                    const uint32_t light = w / n;
-                    trace((uint64_t)light * A.shadow_cap + first + (w - light * n));
+            if constexpr (LEAN) {
+                for (uint32_t part = 0; part < LEAN_TAKE && c + part < total; part += 64u) {
+                    const uint32_t i = c + part + lane_id();
+                    if (i < total) trace(slot_of(i));
                 }
+            } else {
+                const uint32_t c_end = LEAN_TAKE < total - c ? c + LEAN_TAKE : total;
+                const uint32_t run = chunk > 64u ? LEAN_TAKE : 64u;  // (lanes take new rays only in scenes where that pays)
+                for (uint32_t part = c; part < c_end; part += run) trace_run(w, part, run < c_end - part ? part + run : c_end, 0, true);
             }
         }
-    } else if constexpr (RT_SHADOW_REFILL != 0 && (CULL & 4) == 0) {
-        // A wave owns `chunk` consecutive rays of one light's queue at a time, and a lane whose ray
-        // is finished takes the chunk's next one between two rounds of the walk (once enough lanes are idle
-        // to make the fetch worth its instructions): rays differ widely in the number of rounds and
-        // records they take, and a lane that waited for the slowest of its 64 would idle half the time.
+    } else if constexpr (RT_SHADOW_REFILL != 0 && !LEAN) {
         const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
         const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-        KdDeep<(CULL & 4) == 0> deep;
+        KdDeep<!LEAN> deep;
         KdWalk<CULL, Ctr, OCC> w(S, lds_stack, ctr, deep);
-        for (uint64_t c0 = (uint64_t)first + (uint64_t)wave * chunk; c0 < end; c0 += (uint64_t)n_waves * chunk) {
-            uint32_t next = (uint32_t)c0;
-            const uint32_t c_end = c0 + chunk < end ? (uint32_t)c0 + chunk : end;
-            bool have = false;
-            uint32_t mine = 0;
-            float limit = 0.0f;
-            for (;;) {
-                const uint64_t idle = __ballot(!have);
-                const uint32_t n_idle = (uint32_t)__popcll(idle);
-                if (next < c_end && n_idle >= RT_SHADOW_REFILL) {
-                    const uint32_t idx = next + prefix_count(idle);
-                    next += n_idle;
-                    if (!have && idx < c_end) {
-                        const float4 so = A.sray_o[queue + idx];
-                        const float4 sd = A.sray_d[queue + idx];
-                        w.begin(f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), so.w);
-                        mine = idx;
-                        limit = so.w;
-                        if (w.done) A.sray_blocked[queue + idx] = 0u;  // (misses the scene's box)
-                        else have = true;
-                    }
-                }
-                if (__ballot(have) == 0ull) {
-                    if (next >= c_end) break;
-                    continue;
-                }
-                if (have) {
-                    w.round();
-                    if (w.done) {
-                        A.sray_blocked[queue + mine] = (w.r_hit && w.r.dist <= limit) ? 1u : 0u;
-                        have = false;
-                    }
-                }
-            }
-        }
+        for (uint64_t c0 = (uint64_t)first + (uint64_t)wave * chunk; c0 < end; c0 += (uint64_t)n_waves * chunk)
+            trace_run(w, (uint32_t)c0, c0 + chunk < end ? (uint32_t)c0 + chunk : end, queue, false);
     } else {
         const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
         for (uint32_t k = first + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) trace(queue + k);
@@ -766,30 +781,45 @@ static uint32_t g_cus = 256;  // compute units of the device (init_kernels)
 #ifndef RT_LEVEL0_BLOCK
 #define RT_LEVEL0_BLOCK 256
 #endif
+// Scenes that are not lean whose node array fits LDS (DevScene.nodes_lds): staying blocks with a copy of
+// the nodes, one block of 16 waves per CU, for the deeper levels and the shadow rays.  Measured on rings 4
+// (321 nodes) at 3840x2160: deeper levels 15.0 -> 13.8 ms, shadow rays 17.8 -> 16.6 ms; level 0 would lose
+// (1.33 -> 1.79 ms: its rays are coherent, and the vector L1 serves their node fetches as well).
+#ifndef RT_STAY_GEN_DEEP
+#define RT_STAY_GEN_DEEP 1
+#endif
+#ifndef RT_STAY_GEN_SHADOW
+#define RT_STAY_GEN_SHADOW 1
+#endif
+constexpr int GEN_ID = 2 | 8 | 16, GEN_SH = 2 | 8 | 16;
 constexpr int LEAN_I0 = 5 | (RT_STAY_LEVEL0 ? 8 : 0), LEAN_ID = 6 | (RT_STAY_DEEP ? 8 : 0), LEAN_SH = 6 | (RT_STAY_SHADOW ? 8 : 0);
 static const bool g_lean_stays[5] = {RT_STAY_LEVEL0 != 0, RT_STAY_DEEP != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0};
 // Threads per staying block of each lean kernel: RT_LEAN_BLOCKS_PER_CU blocks fill the waves per SIMD the
 // kernel's register use allows (init_kernels).  [0] k_intersect level 0, [1] deeper levels, [2..4] k_shadow by mode.
 static uint32_t g_lean_block[5] = {512, 512, 512, 512, 512};
+// The same for the staying blocks of scenes that are not lean, one block per CU: [0] k_intersect level 0,
+// [1] deeper levels, [2] k_shadow (mode 0); [0] unused.
+static uint32_t g_gen_block[3] = {1024, 1024, 1024};
 static size_t stack_bytes(const DevScene& S, bool lean_kernel, uint32_t block, bool stays) {
     const size_t entries = lean_kernel ? S.stack_depth : RT_STACK_RING;
-    return entries * block * sizeof(uint2) + (size_t)RT_LANE_WORDS * block * sizeof(uint32_t) +
-           (stays ? (size_t)S.bnd_records * sizeof(float4) : 0);  // (+ the block's copy of the bounding records)
+    // (+ a staying block's copy of the bounding records, or of the nodes)
+    const size_t copy = !stays ? 0 : (lean_kernel ? (size_t)S.bnd_records * sizeof(float4) : (size_t)S.n_nodes * 64u);
+    return entries * block * sizeof(uint2) + (size_t)RT_LANE_WORDS * block * sizeof(uint32_t) + copy;
 }
 
 // Threads per block of the trace kernels.  A block keeps its LDS and wave slots until its slowest
 // wave is done, and waves of incoherent rays in trees of small leaves differ widely: those
 // scenes run one wave per block.  Lean scenes (a few huge sphere leaves) do best with two.
 static uint32_t trace_block(const DevScene& S, bool stays, uint32_t which) {
-    if (stays) return g_lean_block[which];
+    if (stays) return S.lean != 0 ? g_lean_block[which] : g_gen_block[which < 2u ? which : 2u];
     if (which == 0) return RT_LEVEL0_BLOCK;  // (camera rays: tiles next to each other take alike, and four waves share a queue append)
     return S.lean != 0 ? RT_BLOCK : RT_TRACE_BLOCK_GENERAL;
 }
 // `grid` counts blocks of RT_BLOCK threads; a launch of blocks of `tb` threads covers the same
 // number of threads, and a launch of staying blocks never more blocks than stay resident.
-static uint32_t blocks_of(uint32_t grid, uint32_t tb, bool stays) {
+static uint32_t blocks_of(uint32_t grid, uint32_t tb, bool stays, uint32_t per_cu = RT_LEAN_BLOCKS_PER_CU) {
     const uint64_t b = ((uint64_t)grid * RT_BLOCK + tb - 1) / tb;
-    return (uint32_t)(stays ? (b < (uint64_t)g_cus * RT_LEAN_BLOCKS_PER_CU ? b : (uint64_t)g_cus * RT_LEAN_BLOCKS_PER_CU) : b);
+    return (uint32_t)(stays ? (b < (uint64_t)g_cus * per_cu ? b : (uint64_t)g_cus * per_cu) : b);
 }
 
 // Lets the traversal stack use up to the CU's whole 160 KiB of LDS.
@@ -810,6 +840,7 @@ hipError_t init_kernels() {
                          (const void*)k_shadow<LEAN_SH, NoCounters>,
                          (const void*)k_shadow<2, NoCounters, 1>, (const void*)k_shadow<LEAN_SH, NoCounters, 1>,
                          (const void*)k_shadow<2, NoCounters, 2>, (const void*)k_shadow<LEAN_SH, NoCounters, 2>,
+                         (const void*)k_intersect<false, GEN_ID, NoCounters>, (const void*)k_shadow<GEN_SH, NoCounters>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
     for (const void* f : fns) {
         hipFuncAttributes fa;
@@ -834,6 +865,16 @@ hipError_t init_kernels() {
         if (threads > RT_LEAN_BLOCK) threads = RT_LEAN_BLOCK;
         g_lean_block[k] = threads < 64u ? 64u : threads;
     }
+    const void* gen_fns[3] = {nullptr, (const void*)k_intersect<false, GEN_ID, NoCounters>, (const void*)k_shadow<GEN_SH, NoCounters>};
+    for (int k = 1; k < 3; ++k) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, gen_fns[k]);
+        if (e != hipSuccess) return e;
+        const uint32_t regs = ((uint32_t)(fa.numRegs > 0 ? fa.numRegs : 128) + 7u) & ~7u;
+        uint32_t waves = 512u / regs;
+        waves = waves < 1u ? 1u : (waves > 4u ? 4u : waves);  // (a block of RT_LEAN_BLOCK threads is four waves per SIMD)
+        g_gen_block[k] = waves * 4u * 64u;
+    }
     return hipSuccess;
 }
 
@@ -841,9 +882,10 @@ hipError_t init_kernels() {
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
     const bool lean = A.scene.lean != 0;
     const uint32_t which = level == 0 ? 0u : 1u;
-    const bool stays = !work && cull && lean && g_lean_stays[which];
+    const bool gen_stays = !work && cull && !lean && A.scene.nodes_lds != 0u && level > 0 && RT_STAY_GEN_DEEP != 0;
+    const bool stays = gen_stays || (!work && cull && lean && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
-    const dim3 g(blocks_of(grid, tb, stays)), b(tb);
+    const dim3 g(blocks_of(grid, tb, stays, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU)), b(tb);
     const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays);
     if (level == 0) {  // camera rays start outside the scene: the line test alone
         if (work && cull) hipLaunchKernelGGL((k_intersect<true, 1, WorkCounters>), g, b, lds, st, A, level);
@@ -855,6 +897,7 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
         if (work && cull) hipLaunchKernelGGL((k_intersect<false, 2, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<false, 0, WorkCounters>), g, b, lds, st, A, level);
         else if (cull && lean) hipLaunchKernelGGL((k_intersect<false, LEAN_ID, NoCounters>), g, b, lds, st, A, level);
+        else if (gen_stays) hipLaunchKernelGGL((k_intersect<false, GEN_ID, NoCounters>), g, b, lds, st, A, level);
         else if (cull) hipLaunchKernelGGL((k_intersect<false, 2, NoCounters>), g, b, lds, st, A, level);
         else hipLaunchKernelGGL((k_intersect<false, 0, NoCounters>), g, b, lds, st, A, level);
     }
@@ -865,20 +908,23 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
                          hipStream_t st) {
     const bool lean_kernel = !work && cull && A.scene.lean != 0;
     const uint32_t which = 2u + (A.shadow_mode <= 2u ? A.shadow_mode : 0u);
-    const bool stays = lean_kernel && g_lean_stays[which];
+    const bool gen_stays = !work && cull && A.scene.lean == 0 && A.scene.nodes_lds != 0u && A.shadow_mode == 0u && RT_STAY_GEN_SHADOW != 0;
+    const bool stays = gen_stays || (lean_kernel && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
     const size_t lds = stack_bytes(A.scene, lean_kernel, tb, stays);
-    // (a launch of staying blocks covers all lights with one set of blocks)
-    // Rays a wave owns at a time (k_shadow): as many as leave every SIMD its four waves, at most RT_SHADOW_CHUNK.
+    // Rays a wave owns at a time (k_shadow): as many as leave every SIMD its four waves eight times over, at
+    // most RT_SHADOW_CHUNK (staying blocks deal runs out from a counter: RT_SHADOW_CHUNK or 64).
     uint32_t chunk = 64u;
     if (RT_SHADOW_REFILL != 0 && !lean_kernel && A.scene.refill != 0u) {
         // (eight times as many waves as the device holds at once, or the last ones run on a half-empty device)
         const uint64_t rays = (uint64_t)grid * RT_BLOCK * A.scene.n_lights;
-        const uint64_t fair = rays / ((uint64_t)g_cus * 16u * 8u) / 64u * 64u;
+        const uint64_t fair = rays / ((uint64_t)g_cus * 16u * (gen_stays ? 2u : 8u)) / 64u * 64u;
         chunk = (uint32_t)(fair < 64u ? 64u : (fair > RT_SHADOW_CHUNK ? RT_SHADOW_CHUNK : fair));
     }
     const uint32_t grid_c = (uint32_t)(((uint64_t)grid * 64u + chunk - 1u) / chunk);
-    const dim3 g(stays ? blocks_of(grid * A.scene.n_lights, tb, true) : blocks_of(grid_c, tb, false), stays ? 1u : A.scene.n_lights), b(tb);
+    // (a launch of staying blocks covers all lights with one set of blocks)
+    const dim3 g(stays ? blocks_of(grid * A.scene.n_lights, tb, true, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU) : blocks_of(grid_c, tb, false),
+                 stays ? 1u : A.scene.n_lights), b(tb);
     // shadow rays start on a surface, among the primitives, at every level: the behind-origin test pays
     const int mode = cull ? 2 : 0;
     const bool lean = A.scene.lean != 0;
@@ -893,6 +939,7 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
         else hipLaunchKernelGGL((k_shadow<2, NoCounters, 2>), g, b, lds, st, A, first_level, last_level, chunk);
     } else {
         if (mode == 2 && lean) hipLaunchKernelGGL((k_shadow<LEAN_SH, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+        else if (gen_stays) hipLaunchKernelGGL((k_shadow<GEN_SH, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
         else if (mode == 2) hipLaunchKernelGGL((k_shadow<2, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
         else hipLaunchKernelGGL((k_shadow<0, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
     }

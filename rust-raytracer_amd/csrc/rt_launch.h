@@ -17,8 +17,9 @@
 // used up (no wave waits for a slower one, whatever the block's size).  640 threads = 10 waves; two
 // such blocks per CU hold 2 x (10 waves' stacks and lane words + the records) in the 160 KiB of LDS
 // and give every SIMD 5 waves.
-#define RT_LEAN_BLOCK 640
+#define RT_LEAN_BLOCK 1024
 #define RT_LEAN_BLOCKS_PER_CU 2
+#define RT_NODE_LDS_BYTES 24576  // largest node array (64 bytes a node) the staying blocks of a scene that is not lean copy to LDS
 #define RT_LEAN_RECORD_BYTES 24576 // most bounding-record bytes a lean kernel's block copies into LDS
 // Traversal stack of the general kernels: the newest RT_STACK_RING entries of a lane sit in LDS,
 // older ones in the lane's private memory, so that a deep tree does not cost occupancy (every
@@ -61,6 +62,8 @@ struct DevScene {
     uint32_t lean;             // 1: no cones and no polygon run with bounding records anywhere in the scene, and
                                // few enough bounding records for a copy in every block's LDS
     uint32_t bnd_records;      // float4 records in bnd
+    uint32_t n_nodes;          // records in nodes
+    uint32_t nodes_lds;        // 1: not lean, and the node array is small enough for a copy in every staying block's LDS
     uint32_t refill;           // 1: shadow waves own a run of rays and their lanes take the next ray as they finish
                                // (trees of small leaves, where rays differ most in the number of leaves they visit)
     float bg[3];

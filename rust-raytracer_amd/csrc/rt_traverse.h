@@ -679,15 +679,29 @@ __device__ unsigned long long g_phase[8];
 #define RT_PHASE_END() do {} while (0)
 #endif
 
-// The lean kernels' copy of the scene's bounding records in LDS, made by all threads of a block when
-// it starts (behind the traversal stack and the lane words; a barrier follows).
-RT_DEV void stage_records(const DevScene& S, uint2* stack) {
-    f32x4* dst = (f32x4*)((uint32_t*)(stack + S.stack_depth * blockDim.x) + (uint32_t)RT_LANE_WORDS * blockDim.x);
-    for (uint32_t i = threadIdx.x; i < S.bnd_records; i += blockDim.x) {
-        const float4 v = S.bnd[i];
-        f32x4 w;
-        w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-        dst[i] = w;
+// The staying blocks' copies of scene data in LDS, made by all threads of a block when it starts (behind
+// the traversal stack and the lane words; a barrier follows): the bounding records (lean kernels), or the
+// node array (CULL + 16: scenes that are not lean whose tree is small).
+typedef __attribute__((address_space(3))) const u32x4* lds_cu4_ptr;
+template <int CULL>
+RT_DEV void stage_scene(const DevScene& S, uint2* stack) {
+    const uint32_t entries = (CULL & 4) != 0 ? S.stack_depth : (uint32_t)RT_STACK_RING;
+    uint32_t* dst = (uint32_t*)(stack + entries * blockDim.x) + (uint32_t)RT_LANE_WORDS * blockDim.x;
+    if constexpr ((CULL & 4) != 0) {
+        for (uint32_t i = threadIdx.x; i < S.bnd_records; i += blockDim.x) {
+            const float4 v = S.bnd[i];
+            f32x4 w;
+            w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+            ((f32x4*)dst)[i] = w;
+        }
+    }
+    if constexpr ((CULL & 16) != 0) {
+        for (uint32_t i = threadIdx.x; i < S.n_nodes * 4u; i += blockDim.x) {
+            const uint4 v = S.nodes[i];
+            u32x4 w;
+            w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+            ((u32x4*)dst)[i] = w;
+        }
     }
     __syncthreads();
 }
@@ -710,6 +724,7 @@ struct KdWalk {
     KdStack<!LEAN> st;
     uint32_t* lane_words;
     lds_cf4_ptr lrec;
+    lds_cu4_ptr lnodes;  // (CULL + 16) the block's copy of S.nodes
     bool tame, ok_cone, done, r_hit;
     Hit r;
     typename std::conditional<OCCL, Occluder<!LEAN, OCC == 2>, NoOccluder>::type occ;
@@ -721,6 +736,7 @@ struct KdWalk {
         // kernels, the block's copy of the bounding records (stage_records)
         lane_words = (uint32_t*)(stack + (LEAN ? S.stack_depth : (uint32_t)RT_STACK_RING) * stride) + threadIdx.x;
         lrec = (lds_cf4_ptr)(lane_words - threadIdx.x + (uint32_t)RT_LANE_WORDS * stride);
+        lnodes = (lds_cu4_ptr)(lane_words - threadIdx.x + (uint32_t)RT_LANE_WORDS * stride);
         done = true;
         r_hit = false;
     }
@@ -770,10 +786,14 @@ struct KdWalk {
         uint32_t leaf_w = 0xffffffffu;  // a leaf's first word: header of its cylinder run's records, or none
         uint4 q2 = make_uint4(0, 0, 0, 0), q3 = make_uint4(0, 0, 0, 0);
         while (!done && !at_leaf) {
-            const uint4 n0 = S.nodes[cur * 4 + 0];
-            const uint4 n1 = S.nodes[cur * 4 + 1];
-            const uint4 n2 = S.nodes[cur * 4 + 2];
-            const uint4 n3 = S.nodes[cur * 4 + 3];
+            uint4 n0, n1, n2, n3;
+            if constexpr ((CULL & 16) != 0) {
+                const u32x4 a0 = lnodes[cur * 4 + 0], a1 = lnodes[cur * 4 + 1], a2 = lnodes[cur * 4 + 2], a3 = lnodes[cur * 4 + 3];
+                n0 = make_uint4(a0.x, a0.y, a0.z, a0.w); n1 = make_uint4(a1.x, a1.y, a1.z, a1.w);
+                n2 = make_uint4(a2.x, a2.y, a2.z, a2.w); n3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
+            } else {
+                n0 = S.nodes[cur * 4 + 0]; n1 = S.nodes[cur * 4 + 1]; n2 = S.nodes[cur * 4 + 2]; n3 = S.nodes[cur * 4 + 3];
+            }
             const uint32_t axis = n0.y;
             if (axis == AXIS_LEAF) {
                 q2 = n1;
@@ -811,7 +831,7 @@ struct KdWalk {
             }
             if constexpr (MODE != 0) {
                 if (q2.y >= CULL_MIN_SPHERES && tame) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_run_lane<0, MODE == 2, (CULL & 8) != 0>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec);
+                    leaf_run_lane<0, MODE == 2, (CULL & 12) == 12>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec);
                     q2.y = 0u;
                 }
                 RT_PHASE(1);  // sphere hierarchy
