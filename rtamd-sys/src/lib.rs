@@ -1,8 +1,8 @@
 //! Raw bindings to `librtamd.so`: every type and function of `include/rtamd.h`, field for field.
 //! The reference program calls `render::render(&view, &scene, &mut target)` once
 //! (src/render.rs:72, from src/main.rs:41); a host that wants the GPU path flattens its `Scene`
-//! into the plain arrays below and calls `rt_scene_create` + `rt_render` instead
-//! (INTEGRATION.md shows that `render()`).
+//! into the plain arrays below and calls `rt_context_create`, `rt_scene_create` and `rt_render`
+//! instead, in that order, writing into `RenderTarget`'s `values` (row-major f32 RGB).
 //!
 //! This crate cannot be compiled where it was written (no cargo / rustc in that image);
 //! `tests/test_host.py` holds its struct fields and function names to the header's.
