@@ -811,6 +811,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
                          : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
         return RT_OK;
     };
+    bool lit_level0 = false;  // level 0's lighting is queued already
     for (uint32_t level = 0; level <= last_level; ++level) {
         const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
@@ -833,17 +834,25 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
                 const uint32_t first = level < SHADOW_GROUP_FROM ? level : SHADOW_GROUP_FROM;
                 rc = shadow_rays(first, level);
                 if (rc != RT_OK) return rc;
+                if (level == 0 && last_level > 0) {
+                    // Two streams: the camera rays' hits (most of the frame's nodes) are lit as soon as their shadow
+                    // rays are traced, beside the deeper levels -- the lighting kernel waits for HBM, the trace
+                    // kernels for the vector ALUs.
+                    RT_HIP(ctx, fast ? rt_fast::launch_light(A, 0, 0, work, grid0, st2) : rt_exact::launch_light(A, 0, 0, work, grid0, st2));
+                    lit_level0 = true;
+                }
             }
         }
     }
     if (n_lights) {
         {   // direct light of every node of the frame, once all shadow rays are traced: one launch, and
             // no level's shadow rays wait behind an earlier level's lighting
-            uint64_t rays = n_slots;
+            uint64_t rays = lit_level0 ? 0u : n_slots;
             for (uint32_t l = 1; l <= last_level; ++l) rays += ctx->hint_rays[l];
             const uint32_t gl = hinted ? blocks_for(rays, 0x7fffffffu) : grid0 + gridn;
-            RT_HIP(ctx, fast ? rt_fast::launch_light(A, 0, last_level, work, gl, st2)
-                             : rt_exact::launch_light(A, 0, last_level, work, gl, st2));
+            const uint32_t from = lit_level0 ? 1u : 0u;
+            RT_HIP(ctx, fast ? rt_fast::launch_light(A, from, last_level, work, gl, st2)
+                             : rt_exact::launch_light(A, from, last_level, work, gl, st2));
         }
         if (serial) RT_HIP(ctx, hipEventRecord(f.ev_t[f.timed_levels + 1], st));
         RT_HIP(ctx, hipEventRecord(f.ev_shadow, st2));
