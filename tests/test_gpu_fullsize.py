@@ -117,3 +117,24 @@ def test_tetra_at_8k(rtamd, oracle, spd, gpu_ctx):
     for r in (1100, 2160, 3300):
         of, ou, _, _ = o.render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, row_start=r, row_step=h, threads=16)
         assert np.array_equal(bits(cf[r]), bits(of[r])) and np.array_equal(cu[r], ou[r]), r
+
+
+def test_balls_at_8k(rtamd, oracle, spd, gpu_ctx):
+    """The sphere scene at the largest resolution: its first bounce level holds more than four million
+    rays, the size from which the resident blocks of the deeper levels take their rays 512 at a time."""
+    w, h, depth = 7680, 4320, 3
+    text = spd.balls(4, w, h)
+    sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=16)
+    cf, cu, cst = sc.render(rtamd.RenderOptions(max_depth=depth), w, h)
+    ef, eu, est = sc.render(rtamd.RenderOptions(max_depth=depth, exhaustive_leaves=True), w, h)
+    assert np.array_equal(bits(cf), bits(ef)) and np.array_equal(cu, eu)
+    c, e = cst.as_dict(), est.as_dict()
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
+        assert c[k] == e[k], k
+    assert c["rays_primary"] == w * h and c["rays_reflect"] > (1 << 22) and c["rays_shadow"] % 3 == 0
+    assert cst.ray_nodes == c["rays_primary"] + c["rays_reflect"] + c["rays_refract"]
+    del ef, eu
+    o = oracle.OracleScene(text, build_threads=16)
+    for r in (1500, 2600, 3900):
+        of, ou, _, _ = o.render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, row_start=r, row_step=h, threads=16)
+        assert np.array_equal(bits(cf[r]), bits(of[r])) and np.array_equal(cu[r], ou[r]), r
