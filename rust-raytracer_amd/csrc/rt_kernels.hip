@@ -704,10 +704,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
             const F3 bmin = f3(a[0], a[1], a[2]);
             const F3 bmax = f3(a[0] + a[3], a[1] + a[4], a[2] + a[5]);
             const F3 ray = f3(a[9], a[10], a[11]);
-#if RT_FAST
-            ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
-#endif
-            o[0] = aabb_slab_test(bmin, bmax, f3(a[6], a[7], a[8]), ray, a[12], ri) ? 1.0f : 0.0f;
+            // (the traversal's own sequence: the quick decision from reciprocals where it is safe, the
+            // reference's divisions where it is not)
+            ri = ray_inv_of(ray);
+            o[0] = box_passes(bmin, bmax, f3(a[6], a[7], a[8]), ray, a[12], ri) ? 1.0f : 0.0f;
             return;
         }
         case 1: {  // RT_OP_SPHERE

@@ -285,6 +285,27 @@ RT_DEV bool aabb_slab_test(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, co
     return smallest_far >= largest_near && smallest_far >= near_cull;
 }
 
+// What the traversal does with a box: a ray's reciprocals once (ray_inv_of), then per box the quick
+// decision where it is safe and the reference's divisions where it is not.
+RT_DEV RayInv ray_inv_of(F3 ray) {
+    RayInv ri;
+    ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+    const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
+    ri.quick = (ax == 0.0f || (ax >= 1e-30f && ax <= 1e30f)) && (ay == 0.0f || (ay >= 1e-30f && ay <= 1e30f)) &&
+               (az == 0.0f || (az >= 1e-30f && az <= 1e30f));
+    return ri;
+}
+RT_DEV bool box_passes(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, const RayInv& ri) {
+#if RT_FAST
+    return aabb_slab_test(bmin, bmax, src, ray, near_cull, ri);
+#else
+    // the reference's six divisions only where the quotients' order is in doubt
+    bool in_box = false;
+    if (!ri.quick || !aabb_quick(bmin, bmax, src, ray, near_cull, ri.inv, in_box)) in_box = aabb_slab_test(bmin, bmax, src, ray, near_cull, ri);
+    return in_box;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 // Sphere, src/sphere.rs:27-79.  The distance and the normal are split so that the normal
 // is only formed for a hit that becomes the leaf's nearest.

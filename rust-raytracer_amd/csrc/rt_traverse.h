@@ -741,25 +741,11 @@ struct KdWalk {
         r_hit = false;
     }
 
-    RT_DEV bool box_hit(F3 bmin, F3 bmax) const {
-#if RT_FAST
-        return aabb_slab_test(bmin, bmax, src, ray, near, ri);
-#else
-        // the reference's six divisions only where the quotients' order is in doubt
-        bool in_box = false;
-        if (!ri.quick || !aabb_quick(bmin, bmax, src, ray, near, ri.inv, in_box)) in_box = aabb_slab_test(bmin, bmax, src, ray, near, ri);
-        return in_box;
-#endif
-    }
+    RT_DEV bool box_hit(F3 bmin, F3 bmax) const { return box_passes(bmin, bmax, src, ray, near, ri); }
 
     RT_DEV void begin(F3 src_, F3 ray_, float near_, uint32_t ignore_, float limit) {
         src = src_; ray = ray_; near = near_; ignore = ignore_;
-        ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
-        {
-            const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
-            ri.quick = (ax == 0.0f || (ax >= 1e-30f && ax <= 1e30f)) && (ay == 0.0f || (ay >= 1e-30f && ay <= 1e30f)) &&
-                       (az == 0.0f || (az >= 1e-30f && az <= 1e30f));
-        }
+        ri = ray_inv_of(ray);
         a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
         st.sp = 0;
         st.lo = 0;

@@ -50,6 +50,39 @@ def test_aabb_slab_test(rtamd, oracle, gpu_ctx):
     assert (fast.astype(np.uint8) != want).mean() < 1e-3
 
 
+def test_box_decision_of_grazing_rays(rtamd, oracle, gpu_ctx):
+    """The traversal decides most boxes from products with the ray's reciprocals and falls back to the
+    reference's divisions when two quotients are too close to call.  Rays aimed at box edges and corners to
+    within a few ulps, from near and from 10^4 box sizes away, at boxes of ordinary, tiny and zero
+    thickness, with `near` at, just below and just above the entry distance: every decision is the oracle's."""
+    rng = np.random.default_rng(12)
+    n = N
+    corner = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    extent = rng.uniform(0.01, 2, (n, 3)).astype(np.float32)
+    extent[: n // 8] *= np.float32(1e-4)
+    extent[n // 8: n // 6, rng.integers(0, 3)] = 0.0
+    scale = rng.choice(np.array([1.0, 1.0, 30.0, 1e4], np.float32), (n, 1))
+    src = (corner + extent / 2 + rng.normal(size=(n, 3)).astype(np.float32) * 4 * scale).astype(np.float32)
+    # a point on an edge or a corner of the box (each coordinate at the low face, the high face, or inside)
+    pick = rng.integers(0, 3, (n, 3))
+    inside = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    target = corner + np.where(pick == 0, 0, np.where(pick == 1, 1, inside)).astype(np.float32) * extent
+    d = (target.astype(np.float64) - src.astype(np.float64))
+    ray = d.astype(np.float32)
+    # nudge the direction by a few ulps either way, keep some exactly on target; unit length for a third
+    nudge = rng.integers(-3, 4, (n, 3))
+    ray = (ray.view(np.int32) + np.where(rng.random((n, 3)) < 0.5, nudge, 0).astype(np.int32)).view(np.float32)
+    unit = rng.random(n) < 0.33
+    ray[unit] = (ray[unit] / np.linalg.norm(ray[unit].astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    t_entry = np.where(unit, np.linalg.norm(d, axis=1), 1.0)
+    near = (t_entry * rng.choice(np.array([0.0, 0.5, 1.0 - 1e-6, 1.0, 1.0 + 1e-6, 1.5]), n)).astype(np.float32)
+    rows = np.concatenate([corner, extent, src, ray, near[:, None]], axis=1)
+    want = oracle.aabb_batch(np.concatenate([corner, extent], axis=1), src, ray, near)
+    got = gpu_ctx.debug_eval(rtamd.OP_AABB, rows, 1, rtamd.FP_EXACT)[:, 0]
+    assert np.array_equal(got.astype(np.uint8), want)
+    assert 0.2 < want.mean() < 0.8
+
+
 def shape_case(rtamd, oracle, gpu_ctx, op, kind, data8, verts, centre, spread, seed):
     rng = np.random.default_rng(seed)
     src, ray, near = rays_towards(rng, N, np.asarray(centre, np.float32), spread)
