@@ -326,7 +326,8 @@ int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32_t fp_mode,
                        float* out_dist, float* out_normal);
 
 enum {
-    RT_OP_AABB = 0,     /* in: box6(corner,extent) src3 ray3 near1 = 13 floats; out: 1 (0/1) */
+    RT_OP_AABB = 0,     /* in: box6(corner,extent) src3 ray3 near1 = 13 floats; out: 1 (0/1), the traversal's decision;
+                         * with out_stride >= 2 a second column: the same by the lean kernels' arithmetic */
     RT_OP_SPHERE = 1,   /* in: sphere4 src3 ray3 near1 = 11; out: hit dist n3 = 5 */
     RT_OP_CONE = 2,     /* in: cone8 src3 ray3 near1 = 15; out: 5 */
     RT_OP_POLYGON = 3,  /* in: src3 ray3 near1 = 7 (+ shared vertex list); out: 5 */

@@ -611,6 +611,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     memcpy(d.bg, sd.background, sizeof(d.bg));
     memcpy(d.root_min, sc->tree.nodes[0].bmin, sizeof(d.root_min));
     memcpy(d.root_max, sc->tree.nodes[0].bmax, sizeof(d.root_max));
+    d.reach = 0.0f;
+    for (int k = 0; k < 3; ++k) d.reach = std::max(d.reach, std::max(std::fabs(d.root_min[k]), std::fabs(d.root_max[k])));
     if (d.stack_depth > RT_STACK_RING + RT_STACK_DEEP)
         return fail(ctx, RT_ERR_UNSUPPORTED, "space partition deeper than the device traversal stack (64 levels)");
     // a copy of the scene, with this partition, on each further device of the context

@@ -694,8 +694,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
     float* o = out + i * os;
     NoCounters ctr;
     RayInv ri;
-    ri.inv = f3(0.0f, 0.0f, 0.0f);
-    ri.quick = false;
     float t = 0.0f;
     F3 nn = f3(0, 0, 0);
     bool ok = false;
@@ -706,8 +704,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_eval(uint32_t op, uint64_t n
             const F3 ray = f3(a[9], a[10], a[11]);
             // (the traversal's own sequence: the quick decision from reciprocals where it is safe, the
             // reference's divisions where it is not)
-            ri = ray_inv_of(ray);
-            o[0] = box_passes(bmin, bmax, f3(a[6], a[7], a[8]), ray, a[12], ri) ? 1.0f : 0.0f;
+            const float reach = fmaxf(fmaxf(fmaxf(fabsf(bmin.x), fabsf(bmin.y)), fabsf(bmin.z)), fmaxf(fmaxf(fabsf(bmax.x), fabsf(bmax.y)), fabsf(bmax.z)));
+            ri = ray_inv_of(f3(a[6], a[7], a[8]), ray, reach);
+            o[0] = box_passes<false>(bmin, bmax, f3(a[6], a[7], a[8]), ray, a[12], ri) ? 1.0f : 0.0f;
+            if (os > 1) o[1] = box_passes<true>(bmin, bmax, f3(a[6], a[7], a[8]), ray, a[12], ri) ? 1.0f : 0.0f;  // (the lean kernels' form)
             return;
         }
         case 1: {  // RT_OP_SPHERE

@@ -68,6 +68,7 @@ struct DevScene {
                                // (trees of small leaves, where rays differ most in the number of leaves they visit)
     float bg[3];
     float root_min[3], root_max[3];  // the root node's box
+    float reach;                     // the largest coordinate, in size, of that box (and so of every node's)
 };
 
 struct FrameArgs {

@@ -193,49 +193,37 @@ RT_DEV F3 shade_blinn_phong(const Surface& s, F3 normal, F3 view, F3 ldir, F3 lc
 // ---------------------------------------------------------------------------------------
 // Axis-aligned box slab test, src/shape.rs:84-172.  bmax is fl(corner + extent).
 // ---------------------------------------------------------------------------------------
-struct RayInv {  // per-ray reciprocals of the direction
-    F3 inv;
+struct RayInv {  // per ray, for the box tests
+    F3 inv;      // fl(1 / ray)
+    F3 p;        // exact build: fl(src * inv)
+    float slack; // exact build: what p's rounding adds to the quick decision's margins
     bool quick;  // exact build: the ray may use aabb_quick
 };
 
-// The box test decided from quotients formed as (corner - src) * fl(1 / ray), when that is
-// safe.  Each such product is within 3u (u = 2^-24) of the quotient the reference rounds
-// (1/ray: u, the product: u, the reference's own rounding: u), and so are the largest near and
-// the smallest far value taken over the axes, relative to themselves.  The reference's answer
-// (smallest_far >= largest_near && smallest_far >= near_cull) is therefore known whenever the
-// approximate values keep those two comparisons clear by 6.2u resp. 3.1u of their size (plus
-// 1e-37 for products that underflow); then `hit` is the reference's answer and the function
-// returns true.  Otherwise -- a ray that grazes a box edge to the last bits, an infinity, a
-// NaN -- it returns false and the caller runs the reference's divisions.  The ray must have
-// no component other than zero outside 1e-30 .. 1e30 in size (RayInv::quick), so that the
-// reciprocals are finite and normal.
-RT_DEV bool aabb_quick(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, F3 inv, bool& hit) {
-    const F3 to_min = sub(bmin, src);
-    const F3 to_max = sub(bmax, src);
-    float n = -3.402823466e+38f, f = 3.402823466e+38f;
-    bool outside = false;  // a zero component with the origin outside that slab: a miss (src/shape.rs:84-172)
-    if (ray.x != 0.0f) {
-        const float a = to_min.x * inv.x, b = to_max.x * inv.x;
-        n = fminf(a, b); f = fmaxf(a, b);
-    } else {
-        outside = src.x < bmin.x || src.x > bmax.x;
-    }
-    if (ray.y != 0.0f) {
-        const float a = to_min.y * inv.y, b = to_max.y * inv.y;
-        n = fmaxf(n, fminf(a, b)); f = fminf(f, fmaxf(a, b));
-    } else {
-        outside = outside || src.y < bmin.y || src.y > bmax.y;
-    }
-    if (ray.z != 0.0f) {
-        const float a = to_min.z * inv.z, b = to_max.z * inv.z;
-        n = fmaxf(n, fminf(a, b)); f = fminf(f, fmaxf(a, b));
-    } else {
-        outside = outside || src.z < bmin.z || src.z > bmax.z;
-    }
-    const float m1 = __builtin_fmaf(fmaxf(fabsf(f), fabsf(n)), 3.7e-7f, 1e-37f);  // 6.2u
-    const float m2 = __builtin_fmaf(fabsf(f), 1.85e-7f, 1e-37f);                  // 3.1u
-    hit = !outside && f >= n && f >= near_cull;
-    return outside || (fabsf(f - n) > m1 && fabsf(f - near_cull) > m2);
+// The box test decided from approximate quotients where that is safe.  The reference forms
+// R = fl(fl(corner - src) / ray) for six corners' coordinates and compares the largest near and the
+// smallest far value with each other and with near_cull (src/shape.rs:84-172).  Here each quotient is
+// one fused multiply-add, A = fl(corner * inv - p) with inv = fl(1 / ray), p = fl(src * inv):
+//     A = [ (corner - src)/ray (1 + e_inv) - (src/ray)(1 + e_inv) e_p ] (1 + e_fma),   |e| <= u = 2^-24,
+// so |A - R| <= 4u |R| + 1.01u |p|.  Largest-near and smallest-far are maxima and minima of such
+// values and inherit the bound.  The reference's answer (smallest_far >= largest_near &&
+// smallest_far >= near_cull) is therefore known whenever the approximate values keep those two
+// comparisons clear by 8.3u of the larger value + 2.1u max|p| resp. 4.15u |far| + 1.05u max|p| (plus
+// 1e-37 for results that underflow); then `hit` is the reference's answer and the function returns
+// true.  Otherwise -- a ray that grazes a box edge to the last bits -- it returns false and the
+// caller runs the reference's divisions.  RayInv::quick keeps away the rays this arithmetic cannot
+// take: a zero component (the reference then tests the origin against the slab), components outside
+// 1e-30 .. 1e30 in size, and origins or boxes so far out that a product could overflow.
+RT_DEV bool aabb_quick(F3 bmin, F3 bmax, float near_cull, const RayInv& ri, bool& hit) {
+    const float ax = __builtin_fmaf(bmin.x, ri.inv.x, -ri.p.x), bx = __builtin_fmaf(bmax.x, ri.inv.x, -ri.p.x);
+    const float ay = __builtin_fmaf(bmin.y, ri.inv.y, -ri.p.y), by = __builtin_fmaf(bmax.y, ri.inv.y, -ri.p.y);
+    const float az = __builtin_fmaf(bmin.z, ri.inv.z, -ri.p.z), bz = __builtin_fmaf(bmax.z, ri.inv.z, -ri.p.z);
+    const float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float m1 = __builtin_fmaf(fmaxf(fabsf(f), fabsf(n)), 4.95e-7f, ri.slack);  // 8.3u + 2.1u max|p|
+    const float m2 = __builtin_fmaf(fabsf(f), 2.48e-7f, ri.slack);                    // 4.15u + (2.1u max|p|)
+    hit = f >= n && f >= near_cull;
+    return fabsf(f - n) > m1 && fabsf(f - near_cull) > m2;  // (a NaN anywhere: not clear)
 }
 
 RT_DEV bool aabb_slab_test(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, const RayInv& ri) {
@@ -287,21 +275,43 @@ RT_DEV bool aabb_slab_test(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, co
 
 // What the traversal does with a box: a ray's reciprocals once (ray_inv_of), then per box the quick
 // decision where it is safe and the reference's divisions where it is not.
-RT_DEV RayInv ray_inv_of(F3 ray) {
+// `reach`: no coordinate of any box the ray will meet is larger in size (the root's box holds them all).
+RT_DEV RayInv ray_inv_of(F3 src, F3 ray, float reach) {
     RayInv ri;
     ri.inv = f3(1.0f / ray.x, 1.0f / ray.y, 1.0f / ray.z);
+    ri.p = f3(src.x * ri.inv.x, src.y * ri.inv.y, src.z * ri.inv.z);
     const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
-    ri.quick = (ax == 0.0f || (ax >= 1e-30f && ax <= 1e30f)) && (ay == 0.0f || (ay >= 1e-30f && ay <= 1e30f)) &&
-               (az == 0.0f || (az >= 1e-30f && az <= 1e30f));
+    const float far_out = fmaxf(fmaxf(fabsf(src.x), fabsf(src.y)), fabsf(src.z)) + reach;
+    // (components of 1e-30 at least: reciprocals of 1e30 at most; times far_out below 1e37: no product overflows)
+    ri.quick = ax >= 1e-30f && ax <= 1e30f && ay >= 1e-30f && ay <= 1e30f && az >= 1e-30f && az <= 1e30f &&
+               far_out * fmaxf(fmaxf(fabsf(ri.inv.x), fabsf(ri.inv.y)), fabsf(ri.inv.z)) < 1e37f;
+    ri.slack = __builtin_fmaf(fmaxf(fmaxf(fabsf(ri.p.x), fabsf(ri.p.y)), fabsf(ri.p.z)), 1.26e-7f, 1e-37f);
     return ri;
 }
+// The same from A = fl(fl(corner - src) * inv): two operations per quotient instead of one, but no
+// per-ray products to keep (the kernels of lean scenes, whose rays meet two or three boxes, are
+// short of registers).  |A - R| <= 3u |R|: margins 6.2u and 3.1u.
+RT_DEV bool aabb_quick_lean(F3 bmin, F3 bmax, F3 src, float near_cull, F3 inv, bool& hit) {
+    const float ax = (bmin.x - src.x) * inv.x, bx = (bmax.x - src.x) * inv.x;
+    const float ay = (bmin.y - src.y) * inv.y, by = (bmax.y - src.y) * inv.y;
+    const float az = (bmin.z - src.z) * inv.z, bz = (bmax.z - src.z) * inv.z;
+    const float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float m1 = __builtin_fmaf(fmaxf(fabsf(f), fabsf(n)), 3.7e-7f, 1e-37f);  // 6.2u
+    const float m2 = __builtin_fmaf(fabsf(f), 1.85e-7f, 1e-37f);                  // 3.1u
+    hit = f >= n && f >= near_cull;
+    return fabsf(f - n) > m1 && fabsf(f - near_cull) > m2;
+}
+template <bool LEAN = false>
 RT_DEV bool box_passes(F3 bmin, F3 bmax, F3 src, F3 ray, float near_cull, const RayInv& ri) {
 #if RT_FAST
     return aabb_slab_test(bmin, bmax, src, ray, near_cull, ri);
 #else
     // the reference's six divisions only where the quotients' order is in doubt
     bool in_box = false;
-    if (!ri.quick || !aabb_quick(bmin, bmax, src, ray, near_cull, ri.inv, in_box)) in_box = aabb_slab_test(bmin, bmax, src, ray, near_cull, ri);
+    bool clear = false;
+    if (ri.quick) clear = LEAN ? aabb_quick_lean(bmin, bmax, src, near_cull, ri.inv, in_box) : aabb_quick(bmin, bmax, near_cull, ri, in_box);
+    if (!clear) in_box = aabb_slab_test(bmin, bmax, src, ray, near_cull, ri);
     return in_box;
 #endif
 }

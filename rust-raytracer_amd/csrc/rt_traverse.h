@@ -741,11 +741,11 @@ struct KdWalk {
         r_hit = false;
     }
 
-    RT_DEV bool box_hit(F3 bmin, F3 bmax) const { return box_passes(bmin, bmax, src, ray, near, ri); }
+    RT_DEV bool box_hit(F3 bmin, F3 bmax) const { return box_passes<LEAN>(bmin, bmax, src, ray, near, ri); }
 
     RT_DEV void begin(F3 src_, F3 ray_, float near_, uint32_t ignore_, float limit) {
         src = src_; ray = ray_; near = near_; ignore = ignore_;
-        ri = ray_inv_of(ray);
+        ri = ray_inv_of(src, ray, S.reach);
         a = dot(ray, ray);  // src/sphere.rs:51, the same for every sphere
         st.sp = 0;
         st.lo = 0;

@@ -43,8 +43,8 @@ def test_aabb_slab_test(rtamd, oracle, gpu_ctx):
     src[N // 2: N // 2 + 500] = corner[N // 2: N // 2 + 500]  # rays starting on a box corner
     rows = np.concatenate([corner, extent, src, ray, near[:, None]], axis=1)
     want = oracle.aabb_batch(np.concatenate([corner, extent], axis=1), src, ray, near)
-    got = gpu_ctx.debug_eval(rtamd.OP_AABB, rows, 1, rtamd.FP_EXACT)[:, 0]
-    assert np.array_equal(got.astype(np.uint8), want)
+    got = gpu_ctx.debug_eval(rtamd.OP_AABB, rows, 2, rtamd.FP_EXACT)
+    assert np.array_equal(got[:, 0].astype(np.uint8), want) and np.array_equal(got[:, 1].astype(np.uint8), want)
     assert 0.05 < want.mean() < 0.95
     fast = gpu_ctx.debug_eval(rtamd.OP_AABB, rows, 1, rtamd.FP_FAST)[:, 0]
     assert (fast.astype(np.uint8) != want).mean() < 1e-3
@@ -78,8 +78,9 @@ def test_box_decision_of_grazing_rays(rtamd, oracle, gpu_ctx):
     near = (t_entry * rng.choice(np.array([0.0, 0.5, 1.0 - 1e-6, 1.0, 1.0 + 1e-6, 1.5]), n)).astype(np.float32)
     rows = np.concatenate([corner, extent, src, ray, near[:, None]], axis=1)
     want = oracle.aabb_batch(np.concatenate([corner, extent], axis=1), src, ray, near)
-    got = gpu_ctx.debug_eval(rtamd.OP_AABB, rows, 1, rtamd.FP_EXACT)[:, 0]
-    assert np.array_equal(got.astype(np.uint8), want)
+    got = gpu_ctx.debug_eval(rtamd.OP_AABB, rows, 2, rtamd.FP_EXACT)
+    assert np.array_equal(got[:, 0].astype(np.uint8), want)  # the general kernels' arithmetic
+    assert np.array_equal(got[:, 1].astype(np.uint8), want)  # the lean kernels'
     assert 0.2 < want.mean() < 0.8
 
 
