@@ -165,19 +165,20 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
     uint32_t n_refl = 0, n_refr = 0;        // rays appended, counted by lane ...
     uint32_t block_refl = 0, block_refr = 0, step = 0;  // ... or by the block's first thread, for all of its waves
 
-    // Lean kernels: a wave takes the next 64 rays of the level until none are left.  The others stride
-    // over the level (blockDim.x, not RT_BLOCK: scenes with small leaves run in smaller blocks).
-    constexpr bool LEAN = (CULL & 8) != 0;  // (the staying blocks of a lean scene's deeper levels)
+    // Staying blocks (CULL + 8: the deeper levels of lean scenes and of small trees): a wave takes the next
+    // 64 rays of the level until none are left.  The others stride over the level (by blockDim.x, not
+    // RT_BLOCK: the block size differs from kernel to kernel).
+    constexpr bool STAYS = (CULL & 8) != 0;
     // Queue appends: by every wave for itself, or by all waves of a block together (below).  Staying
     // blocks' waves take rays on their own and have no common step to meet at.
-    const bool by_wave = LEAN || blockDim.x <= 64u;
+    const bool by_wave = STAYS || blockDim.x <= 64u;
     // (rays per visit to the counter: few where a level is small, so that every wave gets some; more on
     // big levels, where one address would not take an atomic per 64 rays fast enough)
     const uint32_t lean_take = count >= (1u << 22) ? LEAN_TAKE : 64u;
     uint32_t lean_next = 0, lean_left = 0;
-    for (uint32_t chunk = LEAN ? 0u : blockIdx.x * blockDim.x; LEAN || chunk < count; chunk += gridDim.x * blockDim.x) {
+    for (uint32_t chunk = STAYS ? 0u : blockIdx.x * blockDim.x; STAYS || chunk < count; chunk += gridDim.x * blockDim.x) {
         uint32_t i = chunk + threadIdx.x;
-        if constexpr (LEAN) {
+        if constexpr (STAYS) {
             if (lean_left == 0u) {
                 uint32_t c = 0;
                 if (lane_id() == 0) c = atomicAdd(&A.work_next[level], lean_take);
