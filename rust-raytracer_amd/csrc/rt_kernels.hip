@@ -136,6 +136,17 @@ RT_DEV bool fetch_ray(const FrameArgs& A, uint32_t i, uint32_t node, Ray& r) {
     return true;
 }
 
+// Whether a staying block finds its launch's rays used up already.  Other blocks add to the counter
+// while this one starts, so two waves of a block could read different values: one thread reads, the
+// whole block follows it (every thread then meets, or skips, the barriers after this together).
+RT_DEV bool block_late(const uint32_t* next, uint32_t total, uint32_t* flag) {
+    if (threadIdx.x == 0) *flag = __atomic_load_n(next, __ATOMIC_RELAXED) >= total ? 1u : 0u;
+    __syncthreads();
+    const bool late = *flag != 0u;
+    __syncthreads();  // (the word may be written again right away)
+    return late;
+}
+
 // First shadow-queue slot of `level`: the lit hits of all earlier levels (complete by now).
 RT_DEV uint32_t shadow_first(const FrameArgs& A, uint32_t level) {
     uint32_t s = 0;
@@ -156,7 +167,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
     const uint32_t next_base = base + count;
     if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[level + 1] = next_base;
     if constexpr ((CULL & 8) != 0) {
-        if (A.work_next[level] >= count) return;  // (a block that comes when the level is used up; the same for all its threads)
+        if (block_late(&A.work_next[level], count, &block_ask[0][0])) return;  // a block that comes when the level is used up
         stage_scene<CULL>(S, lds_stack);
     }
     const uint32_t n_lights = S.n_lights;
@@ -431,7 +442,8 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
         // staying blocks: one launch for all lights; a wave takes the next of the launch's (light, slot) pairs
         const uint32_t total = n * S.n_lights;  // (below 2^32: the host caps the queues)
         uint32_t* next = &A.work_next[RT_MAX_LEVELS + first_level];
-        if (*next >= total) return;  // (the same for all threads of the block)
+        __shared__ uint32_t late_flag;
+        if (block_late(next, total, &late_flag)) return;
         stage_scene<CULL>(S, lds_stack);
         KdDeep<!LEAN> deep;
         KdWalk<CULL, Ctr, OCC> w(S, lds_stack, ctr, deep);

@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Known-answer pixels for the reference's eight fixtures (nff/test-*.nff) and two small extra
-scenes, derived here from the reference's formulas and from nothing under oracle/ or the
+"""Known-answer pixels and known-answer space partitions for the reference's eight fixtures
+(nff/test-*.nff), the added fixtures with interior nodes (nff/extra-*.nff) and a few small scenes
+written here, derived from the reference's formulas and from nothing under oracle/ or the
 product: this file imports numpy and json only.
 
     python tests/golden/make_kats.py            # rewrites tests/golden/kats.json
 
-How the answers are made.  `Tracer` below is a scalar evaluation of the reference's render path
-for scenes of fewer than four primitives (the space partition is then one leaf,
-src/space_partition.rs:44, so closest hit = the linear search of :348-385), written from the
-reference's source, formula by formula, with the line each one comes from:
-camera src/render.rs:81-108, Whitted recursion src/scene.rs:82-200, sphere src/sphere.rs:49-76,
-cone src/cone.rs:115-214, polygon src/polygon.rs:61-289, Phong src/phong.rs:35-62, reflect /
-refract / interpolate src/vector_math.rs:51-73 and :440-448, quantisation src/ppm.rs:20-22.
+How the answers are made.  `Tracer` below is a scalar evaluation of the reference's render path,
+written from the reference's source, formula by formula, with the line each one comes from:
+camera src/render.rs:81-108, Whitted recursion src/scene.rs:82-200, bounding boxes
+src/sphere.rs:12-25, src/cone.rs:15-95, src/polygon.rs:11-56, box algebra and the slab test
+src/shape.rs:37-172, construction of the space partition src/space_partition.rs:40-258 (candidate
+order, strict `<`, the two different pairs of inequalities of appraise_split and split, the axis
+cycle), its recursive walk :268-346 (the far child's result REPLACES the near one's) and the
+linear search of a leaf :348-385, sphere src/sphere.rs:49-76, cone src/cone.rs:115-214, polygon
+src/polygon.rs:61-289, Phong src/phong.rs:35-62, Blinn-Phong src/blinn_phong.rs:35-56, reflect /
+refract (with total internal reflection) / interpolate src/vector_math.rs:51-73 and :440-448, the
+scene reader's one-line `c` and six-argument `l` src/nff.rs:206-224, :320-333, :381-410,
+quantisation src/ppm.rs:20-22.  For every scene whose partition has interior nodes the float32
+partition itself (boxes, axes, planes, leaf lists, as bit patterns) is stored as well, and the
+tests hold the product's builder and the oracle's to it.
 Every pixel is evaluated twice, in numpy float32 (the reference's arithmetic type, one rounding
 per operation as in its scalar code) and in float64; a pixel becomes a known answer only when
 both give the same byte within 1 -- so no answer hangs on a rounding accident -- and the float32
@@ -79,13 +87,16 @@ pp 3
 
 
 class Tracer:
-    """The reference's render path for single-leaf scenes, in arithmetic type T."""
+    """The reference's render path in arithmetic type T.  blinn: the --blinn-phong flag
+    (src/main.rs:24-34): every `f` line then makes a Blinn-Phong surface (src/nff.rs:286-306); the
+    surface in force before the first `f` is Phong either way (:352-360)."""
 
-    def __init__(self, text, T):
+    def __init__(self, text, T, blinn=False):
         self.T = T
+        self.blinn = blinn
         self.lights, self.prims = [], []
         self.background = self.vec(1, 1, 1)  # src/scene.rs:26
-        surface = dict(color=self.vec(1, 1, 1), kd=T(1), ks=T(0), shine=T(1), refl=T(0), trans=T(0), ior=T(1))  # src/nff.rs:352-360
+        surface = dict(color=self.vec(1, 1, 1), kd=T(1), ks=T(0), shine=T(1), refl=T(0), trans=T(0), ior=T(1), blinn=False)  # src/nff.rs:352-360
         lines = text.splitlines()
         k = 0
         while k < len(lines):
@@ -106,9 +117,11 @@ class Tracer:
             elif cmd == "l":
                 self.lights.append((self.vec(*args[:3]), self.vec(*args[3:6]) if len(args) == 6 else self.vec(1, 1, 1)))
             elif cmd == "f":  # src/nff.rs:270-300: reflectance := ks
-                surface = dict(color=self.vec(*args[:3]), kd=args[3], ks=args[4], shine=args[5], refl=args[4], trans=args[6], ior=args[7])
+                surface = dict(color=self.vec(*args[:3]), kd=args[3], ks=args[4], shine=args[5], refl=args[4], trans=args[6], ior=args[7], blinn=blinn)
             elif cmd == "s":
                 self.prims.append(("sphere", self.vec(*args[:3]), args[3], surface))
+            elif cmd == "c" and len(args) == 8:  # src/nff.rs:206-224, :405-407: base and apex on the command's own line
+                self.prims.append(("cone", self.vec(*args[:3]), args[3], self.vec(*args[4:7]), args[7], surface))
             elif cmd == "c":
                 b = [T(x) for x in lines[k].split()]
                 a = [T(x) for x in lines[k + 1].split()]
@@ -125,7 +138,7 @@ class Tracer:
                 else:           # src/nff.rs:177-178
                     nrms = [self.normalized(self.vec(*r[3:6])) for r in rows]
                 self.prims.append(("polygon", pts, nrms, surface))
-        assert len(self.prims) < 4, "single-leaf scenes only"
+        self.root = self.build_partition()
 
     # ---- vector helpers: every operation rounds once in T, in the reference's order
     def vec(self, x, y, z):
@@ -261,15 +274,170 @@ class Tracer:
         s = rev[0] / (rev[0] - fwd[0])
         return t, self.normalized(self.interpolate(fn, rn, s))
 
-    def closest(self, src, ray, near, ignore):  # src/space_partition.rs:348-385
+    # ---- bounding boxes: (corner, extent), the far corner always re-derived as corner + extent (src/shape.rs:37-39)
+    def bbox(self, p):
+        T = self.T
+        if p[0] == "sphere":  # src/sphere.rs:12-25
+            _, c, r, _ = p
+            return self.vec(c[0] - r, c[1] - r, c[2] - r), self.vec(r * T(2), r * T(2), r * T(2))
+        if p[0] == "cone":  # src/cone.rs:30-94
+            _, base, base_r, apex, apex_r, _ = p
+            n = self.normalized(apex - base)
+            scale = []
+            for k in range(3):
+                unit = self.vec(*[1 if j == k else 0 for j in range(3)])
+                pk = unit - n * n[k]
+                mk = self.magnitude(pk)
+                scale.append(pk[k] / mk if mk > 0 else T(0))
+            lo, hi = [], []
+            for k in range(3):
+                be, ae = base_r * scale[k], apex_r * scale[k]
+                lo.append(min(base[k] - be, apex[k] - ae))
+                hi.append(max(base[k] + be, apex[k] + ae))
+            return self.vec(*lo), self.vec(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2])
+        _, pts, _, _ = p  # src/polygon.rs:11-56
+        lo = [pts[0][k] for k in range(3)]
+        hi = list(lo)
+        for q in pts[1:]:
+            for k in range(3):
+                if q[k] < lo[k]:
+                    lo[k] = q[k]
+                if q[k] > hi[k]:
+                    hi[k] = q[k]
+        return self.vec(*lo), self.vec(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2])
+
+    def expand_to_fit(self, a, b):  # src/shape.rs:59-82
+        lo = [min(a[0][k], b[0][k]) for k in range(3)]
+        fa, fb = a[0] + a[1], b[0] + b[1]
+        hi = [max(fa[k], fb[k]) for k in range(3)]
+        return self.vec(*lo), self.vec(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2])
+
+    def surface_area(self, box):  # src/shape.rs:45-49
+        e, two = box[1], self.T(2)
+        return e[0] * e[1] * two + e[1] * e[2] * two + e[0] * e[2] * two
+
+    def box_hit(self, box, src, ray, near_cull):  # src/shape.rs:84-172
+        T = self.T
+        corner, extent = box
+        largest_near, smallest_far = T(np.finfo(T).min), T(np.finfo(T).max)
+        to_min = corner - src
+        to_max = corner + extent - src
+        for k in range(3):
+            if ray[k] != 0:
+                a, b = to_min[k] / ray[k], to_max[k] / ray[k]
+                lo, hi = (a, b) if a < b else (b, a)
+                if k == 0:  # the x slab assigns, y and z tighten
+                    largest_near, smallest_far = lo, hi
+                else:
+                    if lo > largest_near:
+                        largest_near = lo
+                    if hi < smallest_far:
+                        smallest_far = hi
+            elif src[k] < corner[k] or src[k] > corner[k] + extent[k]:
+                return False
+        return bool(smallest_far >= largest_near and smallest_far >= near_cull)
+
+    # ---- construction of the space partition (src/space_partition.rs:40-258)
+    def appraise_split(self, items, axis, plane):  # :100-149
+        T = self.T
+        under_count = over_count = 0
+        under_box = over_box = None
+        for _, box in items:
+            if box[0][axis] < plane:
+                under_count += 1
+                under_box = box if under_box is None else self.expand_to_fit(under_box, box)
+            if (box[0] + box[1])[axis] >= plane:
+                over_count += 1
+                over_box = box if over_box is None else self.expand_to_fit(over_box, box)
+        if under_box is not None and over_box is not None:
+            cost = self.surface_area(under_box) * T(under_count) + self.surface_area(over_box) * T(over_count)
+        elif under_box is not None:
+            cost = self.surface_area(under_box) * T(under_count)
+        elif over_box is not None:
+            cost = self.surface_area(over_box) * T(over_count)
+        else:
+            cost = T(0)
+        return under_box, over_box, cost
+
+    def find_splitting_plane(self, items, axis, no_split_cost):  # :40-97
+        if len(items) < 4:
+            return None
+        min_cost, best_plane, best_over, best_under = no_split_cost, self.T(0), None, None
+        for _, box in items:
+            for plane in (box[0][axis], (box[0] + box[1])[axis]):  # the box's min corner, then its max corner
+                under_box, over_box, cost = self.appraise_split(items, axis, plane)
+                if cost < min_cost:
+                    best_under, best_over, best_plane, min_cost = under_box, over_box, plane, cost
+        if best_over is None or best_under is None:
+            return None
+        if min_cost < no_split_cost:
+            return best_under, best_over, best_plane
+        return None
+
+    def build_node(self, items, axis, box, depth=0):  # :223-258
+        assert depth < 64, "the reference's construction does not terminate on this scene"
+        no_split_cost = self.surface_area(box) * self.T(len(items))
+        decision = self.find_splitting_plane(items, axis, no_split_cost)
+        if decision is None:
+            return dict(box=box, leaf=[i for i, _ in items])
+        under_box, over_box, plane = decision
+        over = [it for it in items if (it[1][0] + it[1][1])[axis] > plane]   # split, :151-172: NOT the
+        under = [it for it in items if it[1][0][axis] <= plane]             # inequalities of appraise_split
+        nxt = (axis + 1) % 3
+        return dict(box=box, axis=axis, plane=plane, over=self.build_node(over, nxt, over_box, depth + 1),
+                    under=self.build_node(under, nxt, under_box, depth + 1))
+
+    def build_partition(self):  # :197-221
+        if not self.prims:
+            return dict(box=(self.vec(0, 0, 0), self.vec(0, 0, 0)), leaf=[])
+        items = [(i, self.bbox(p)) for i, p in enumerate(self.prims)]
+        total = items[0][1]
+        for _, box in items[1:]:
+            total = self.expand_to_fit(total, box)
+        return self.build_node(items, 0, total)
+
+    def flat_tree(self):
+        """Preorder (node, under subtree, over subtree): boxes, axis (-1 = leaf), plane, leaf sizes, leaf lists."""
+        boxes, axis, plane, counts, refs = [], [], [], [], []
+        def go(n):
+            boxes.append([float(x) for x in n["box"][0]] + [float(x) for x in n["box"][1]])
+            if "leaf" in n:
+                axis.append(-1); plane.append(0.0); counts.append(len(n["leaf"])); refs.extend(n["leaf"])
+            else:
+                axis.append(n["axis"]); plane.append(float(n["plane"])); counts.append(0)
+                go(n["under"]); go(n["over"])
+        go(self.root)
+        return boxes, axis, plane, counts, refs
+
+    # ---- the walk (src/space_partition.rs:268-385)
+    def leaf_closest(self, leaf, src, ray, near, ignore):  # :348-385
         best = None
-        for idx, p in enumerate(self.prims):
+        for idx in leaf:
             if idx == ignore:
                 continue
+            p = self.prims[idx]
             h = {"sphere": self.hit_sphere, "cone": self.hit_cone, "polygon": self.hit_polygon}[p[0]](p, src, ray, near)
             if h is not None and (best is None or h[0] < best[0]):
                 best = (h[0], h[1], idx)
         return best
+
+    def walk(self, node, src, ray, near, ignore):  # :268-346
+        if not self.box_hit(node["box"], src, ray, near):
+            return None
+        if "leaf" in node:
+            return self.leaf_closest(node["leaf"], src, ray, near, ignore)
+        axis, plane = node["axis"], node["plane"]
+        if src[axis] < plane:
+            first, second, beyond = node["under"], node["over"], (lambda e: e > plane)
+        else:
+            first, second, beyond = node["over"], node["under"], (lambda e: e < plane)
+        r = self.walk(first, src, ray, near, ignore)
+        if r is None or beyond((src + ray * r[0])[axis]):
+            return self.walk(second, src, ray, near, ignore)  # instead of r, whatever it returns
+        return r
+
+    def closest(self, src, ray, near, ignore):
+        return self.walk(self.root, src, ray, near, ignore)
 
     # ---- shading and recursion
     def phong(self, s, normal, view, ldir, lcol):  # src/phong.rs:35-62
@@ -282,6 +450,20 @@ class Tracer:
         ldr = self.dot(rv, ldir)
         if ldr > 0:
             spec = s["ks"] * np.power(ldr, s["shine"])
+        diff = T(0)
+        ndl = self.dot(normal, ldir)
+        if ndl > 0:
+            diff = s["kd"] * ndl
+        return self.vec(lcol[0] * (spec + diff * s["color"][0]), lcol[1] * (spec + diff * s["color"][1]),
+                        lcol[2] * (spec + diff * s["color"][2]))
+
+    def blinn_phong(self, s, normal, view, ldir, lcol):  # src/blinn_phong.rs:35-56 (no back-face way out)
+        T = self.T
+        half = self.normalized(ldir - view)
+        spec = T(0)
+        ndh = self.dot(normal, half)
+        if ndh > 0:
+            spec = s["ks"] * np.power(ndh, s["shine"])
         diff = T(0)
         ndl = self.dot(normal, ldir)
         if ndl > 0:
@@ -307,7 +489,7 @@ class Tracer:
                 ldir = to_l / ld
                 b = self.closest(pos, ldir, T(0), idx)
                 if not (b is not None and b[0] <= ld):
-                    total = total + self.phong(s, normal, ray, ldir, lcol)
+                    total = total + (self.blinn_phong if s["blinn"] else self.phong)(s, normal, ray, ldir, lcol)
             if depth < max_depth:
                 rc = contribution * s["refl"]
                 if rc > cut:
