@@ -83,6 +83,121 @@ pp 3
 3 1.3 0 -1 0.5 0
 3 -1 -1.2 -1 -0.3 -0.4
 """,
+    # Total internal reflection (src/vector_math.rs:62-73, the `else` branch).  The middle of the view
+    # meets a glass face head-on (index 1.5: refracted(n, 1.5) of a head-on ray is the ray itself), then
+    # the back of a second glass face turned 45 degrees: leaving glass, refracted(-n, 1/1.5) has
+    # a = 1 - (1 - 0.5) * 2.25 < 0, so the ray is mirrored instead, straight down onto a matt floor lit
+    # from the side.  Both faces shade to nothing themselves (kd = ks = 0).
+    "kat-tir": """b 0 0 0
+v
+from 0 0 0
+at 1 0 0
+up 0 1 0
+angle 45
+hither 0.1
+resolution 512 512
+l 3 -0.5 2.5
+f 1 1 1 0 0 1 0.9 1.5
+p 4
+2 0.5 0.5
+2 0.5 -0.5
+2 -0.5 -0.5
+2 -0.5 0.5
+p 4
+2.5 0.5 -0.6
+2.5 0.5 0.6
+3.5 -0.5 0.6
+3.5 -0.5 -0.6
+f 0.2 0.8 0.4 1 0 1 0 0
+p 4
+0 -2 -3
+0 -2 3
+6 -2 3
+6 -2 -3
+""",
+    # A cylinder (`c` with equal radii: dr = 0 in src/cone.rs:155-171) given on one line
+    # (src/nff.rs:206-224) under a coloured light (six-argument `l`, :320-333) at the eye.
+    "kat-cylinder": """b 0 0 0
+v
+from 0 0 0
+at 1 0 0
+up 0 1 0
+angle 45
+hither 0.1
+resolution 512 512
+l 0 0 0 1 0.5 0.25
+f 1 1 1 0.6 0.4 4 0 0
+c 3 -1 0 0.5 3 1 0 0.5
+""",
+    # Fifteen primitives of every kind (quads, a pentagon, a patch, spheres, a glass sphere, cylinders
+    # on one and two lines, a cone proper) in a strip along x, so that the construction splits it.
+    "kat-mixed": """b 0.05 0.1 0.2
+v
+from 2 -10 5
+at 0 0 0.5
+up 0 0 1
+angle 58
+hither 0.5
+resolution 256 256
+l 8 -6 10
+l -6 -8 7 0.9 0.7 0.5
+f 0.8 0.8 0.8 0.8 0.2 8 0 0
+p 4
+-6 -1.5 0
+-4 -1.5 0
+-4 1.5 0
+-6 1.5 0
+p 4
+-4 -1.5 0
+-2 -1.5 0
+-2 1.5 0
+-4 1.5 0
+p 4
+-2 -1.5 0
+0 -1.5 0
+0 1.5 0
+-2 1.5 0
+p 4
+0 -1.5 0
+2 -1.5 0
+2 1.5 0
+0 1.5 0
+p 4
+2 -1.5 0
+4 -1.5 0
+4 1.5 0
+2 1.5 0
+p 4
+4 -1.5 0
+6 -1.5 0
+6 1.5 0
+4 1.5 0
+f 0.9 0.3 0.2 0.4 0.6 30 0 0
+s -5 0 0.8 0.8
+s 5 0.3 0.8 0.8
+f 0.2 0.4 0.9 0.6 0.4 12 0 0
+s 2.9 -0.6 0.7 0.7
+f 1 1 1 0.05 0.1 40 0.85 1.5
+s 0 0 1 1
+f 0.3 0.8 0.3 0.7 0.3 6 0 0
+c -3 0.4 0 0.45 -3 0.4 1.6 0.45
+c
+-1.9 -1.0 0.4 0.3
+-1.1 1.0 0.4 0.3
+f 0.9 0.8 0.2 0.6 0.4 20 0 0
+c 1.5 0.8 0 0.6 1.5 0.8 1.5 0
+f 0.8 0.3 0.8 0.9 0.1 3 0 0
+pp 3
+3.6 1.2 0.1 -0.2 -0.5 1
+4.4 1.4 1.4 0.3 -0.6 0.7
+3.2 1.4 1.2 -0.4 -0.6 0.6
+p 5
+-4.2 -1.2 0.2
+-3.6 -1.3 1.0
+-4.4 -1.0 1.6
+-5.2 -0.7 1.1
+-5.0 -0.8 0.4
+""",
 }
 
 
@@ -567,18 +682,72 @@ PIXELS = {
 }
 
 
+# Scenes sampled on a grid: (scene, blinn, first column, first row, step, columns, rows).  Of the grid's
+# pixels those become known answers whose float32 and float64 bytes agree within 1 (which leaves out
+# silhouettes and the chaotic end of mirror paths); at most GRID_KEEP of them per scene, those that
+# show an object first.
+GRID_SCENES = [
+    ("extra-onplane", False, 20, 20, 24, 10, 10),
+    ("extra-patch", False, 20, 20, 24, 10, 10),
+    ("extra-glass", False, 20, 20, 24, 10, 10),
+    ("extra-glass", True, 32, 32, 24, 9, 9),
+    ("extra-cones", False, 20, 20, 24, 10, 10),
+    ("extra-cones", True, 32, 32, 24, 9, 9),
+    ("kat-mixed", False, 8, 102, 12, 21, 6),
+    ("kat-mixed", True, 14, 106, 12, 20, 5),
+    ("test-sphere", True, 100, 100, 52, 7, 7),
+]
+GRID_KEEP = 12
+
+# Explicit pixels of the scenes written here
+PIXELS.update({
+    "kat-tir": [(256, 256, "the floor, by way of a total internal reflection inside the glass"), (250, 262, "the same"),
+                (256, 200, "the floor, seen directly above the glass"), (256, 40, "background")],
+    "kat-cylinder": [(256, 256, "cylinder, head-on, light at the eye"), (256, 200, "cylinder, same column"), (230, 256, "towards the limb"),
+                     (256, 4, "beyond the open end: background")],
+})
+
+
+def kat_key(name, blinn):
+    return name + ("+blinn" if blinn else "")
+
+
 def make():
-    kats = []
+    kats, trees = [], {}
+    def one(name, blinn, t32, t64, i, j, what, must):
+        c32 = t32.pixel(i, j)
+        b32, b64 = Tracer.quantize(c32), Tracer.quantize(t64.pixel(i, j))
+        ok = max(abs(a - b) for a, b in zip(b32, b64)) <= 1
+        assert ok or not must, (name, i, j, b32, b64, "float32 and float64 disagree: not a known answer")
+        if ok:
+            return {"scene": name, "blinn": blinn, "x": i, "y": j, "rgb": b32, "f32": [float(x) for x in c32], "what": what}
+        return None
+    def keep_tree(name, t32):
+        boxes, axis, plane, counts, refs = t32.flat_tree()
+        if len(axis) > 1 and name not in trees:  # bit patterns: JSON numbers would have to round-trip
+            bits = lambda v: [int(np.float32(x).view(np.uint32)) for x in v]
+            trees[name] = {"boxes": [bits(b) for b in boxes], "axis": axis, "plane": bits(plane), "count": counts, "refs": refs}
     for name, pixels in PIXELS.items():
         text = scene_text(name)
         t32, t64 = Tracer(text, np.float32), Tracer(text, np.float64)
+        keep_tree(name, t32)
         for (i, j, what) in pixels:
-            c32 = t32.pixel(i, j)
-            b32, b64 = Tracer.quantize(c32), Tracer.quantize(t64.pixel(i, j))
-            assert max(abs(a - b) for a, b in zip(b32, b64)) <= 1, (name, i, j, b32, b64, "float32 and float64 disagree: not a known answer")
-            kats.append({"scene": name, "x": i, "y": j, "rgb": b32, "f32": [float(x) for x in c32], "what": what})
-    closed_form_checks({(k["scene"], k["x"], k["y"]): k["rgb"] for k in kats})
-    return kats
+            kats.append(one(name, False, t32, t64, i, j, what, True))
+    for name, blinn, x0, y0, step, nx, ny in GRID_SCENES:
+        text = scene_text(name)
+        t32, t64 = Tracer(text, np.float32, blinn), Tracer(text, np.float64, blinn)
+        keep_tree(name, t32)
+        bg = Tracer.quantize(t32.background)
+        found = [one(name, blinn, t32, t64, x0 + step * a, y0 + step * b, "grid sample", False) for b in range(ny) for a in range(nx)]
+        found = [k for k in found if k is not None]
+        objects = [k for k in found if k["rgb"] != bg]
+        sky = [k for k in found if k["rgb"] == bg]
+        stride = max(1, len(objects) // (GRID_KEEP - 1))
+        chosen = objects[::stride][: GRID_KEEP - 1] + sky[:1]
+        assert len(chosen) >= 6, (name, blinn, len(found), len(objects))
+        kats.extend(chosen)
+    closed_form_checks({(kat_key(k["scene"], k["blinn"]), k["x"], k["y"]): k["rgb"] for k in kats})
+    return kats, trees
 
 
 def closed_form_checks(px):
@@ -587,7 +756,7 @@ def closed_form_checks(px):
     near = lambda a, b: abs(a - b) <= 1
     black = [0, 0, 0]
     for key, rgb in px.items():
-        if key[0].startswith("test-") and key[0] not in ("test-overlap", "test-shadow-1", "test-shadow-2"):
+        if key[0].startswith("test-") and "+" not in key[0] and key[0] not in ("test-overlap", "test-shadow-1", "test-shadow-2"):
             assert rgb[0] == rgb[1] == rgb[2], (key, rgb)  # "white ... on a black background": grey levels only
     # test-triangle / test-square: head-on, light behind the eye on the axis.  At the centre pixel the
     # view direction is (1, +-1/512 tan 22.5deg...) ~ the axis, N.L ~ 1: kd 0.5 + ks 0.5 * (R.L)^1 ~ 1 -> 255.
@@ -625,14 +794,29 @@ def closed_form_checks(px):
     assert all(near(a, int(0.8 * d * 255.9)) or near(a, int(0.8 * d * 255.9 * 0.999)) for a, d in zip(px[("kat-window", 256, 256)], direct))
     seen, bare = px[("kat-window", 108, 256)], px[("kat-window", 96, 256)]
     assert all(0.76 < s / b_ < 0.84 for s, b_ in zip(seen[1:], bare[1:]))  # 0.8 of the light on either side of the pane's edge
+    # kat-tir: 0.9 (the front face's transmittance) x 1 (a back face passes everything on, src/scene.rs:151-165)
+    # x the floor's own colour: kd 1 x N.L x (0.2, 0.8, 0.4), N = (0, 1, 0), L = (0, 1.5, 2.5) / |.| at the
+    # point (3, -2, 0) under the mirror face: N.L = 0.5145.  Without the total reflection the ray would
+    # leave through the tilted face towards +x and find the background: black.
+    ndl = 1.5 / math.hypot(1.5, 2.5)
+    assert all(near(a, int(0.9 * ndl * c * 255.9)) for a, c in zip(px[("kat-tir", 256, 256)], (0.2, 0.8, 0.4))), px[("kat-tir", 256, 256)]
+    assert px[("kat-tir", 256, 40)] == black
+    # kat-cylinder: axis along y through (3, 0, 0), radius 0.5, light at the eye with colour (1, 0.5, 0.25): at the
+    # centre N = -V = L, so N.L = 1 and R.L = 1: light x (ks + kd) = light -> (255, 127, 63); the same all along the
+    # column (N.L = cos of the elevation only through L's y component: N stays (-1, 0, 0), L tilts)
+    assert all(near(a, b) for a, b in zip(px[("kat-cylinder", 256, 256)], (255, 127, 63))), px[("kat-cylinder", 256, 256)]
+    r, g, b = px[("kat-cylinder", 230, 256)]
+    assert r < 255 and near(g, r // 2) and near(b, r // 4)  # dimmer towards the limb, the light's colour ratios kept
+    assert px[("kat-cylinder", 256, 4)] == black
     # test-cone: "lit from the front-right": brighter right of the axis than left of it
     assert px[("test-cone", 300, 256)][0] > px[("test-cone", 212, 256)][0]
     assert px[("test-cone", 256, 20)] == black and px[("test-cone", 120, 400)] == black
 
 
 if __name__ == "__main__":
-    kats = make()
+    kats, trees = make()
     out = os.path.join(HERE, "kats.json")
     with open(out, "w") as f:
-        json.dump({"made_by": "tests/golden/make_kats.py", "scenes": EXTRA_SCENES, "pixels": kats}, f, indent=1)
-    print("wrote %d known-answer pixels to %s" % (len(kats), out))
+        json.dump({"made_by": "tests/golden/make_kats.py", "scenes": EXTRA_SCENES, "trees": trees, "pixels": kats}, f, indent=1)
+    print("wrote %d known-answer pixels over %d scenes and %d partitions to %s"
+          % (len(kats), len({(k["scene"], k["blinn"]) for k in kats}), len(trees), out))
