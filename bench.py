@@ -76,15 +76,29 @@ PEAK_HBM_GBS = 8000.0
 PEAK_PLAIN_TOPS = 78.6
 
 
+def workload_tag(args):
+    """Name of this workload in the file names under profiles/ (tools/r3_profile.sh uses the same)."""
+    res = {(3840, 2160): "4k", (1920, 1080): "1080p", (7680, 4320): "8k"}.get((args.width, args.height), f"{args.width}x{args.height}")
+    lights = f"l{args.lights}" if args.scene == "mount" and args.lights else ""
+    return f"{args.scene}{args.size}{lights}_{res}_depth{args.depth}_{args.fp}"
+
+
+# (the names the profiles of the second round were stored under)
+OLD_TAGS = {"balls4_4k_depth8_exact": "balls4k_depth8_exact"}
+
+
 def measured_traffic(args):
     """HBM-side bytes from the committed PMC profile of this exact workload (tools/profile.sh +
     tools/pmc_sum.py: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over a serial-
     schedule run, FETCH_SIZE doubled as gfx950 needs; counters need rocprofv3, so they are not
-    collected inside this run): (the file's contents, its path relative to the repository), or
-    (None, None) for any other workload."""
-    if (args.scene, args.size, args.width, args.height, args.depth, args.fp) != ("balls", 4, 3840, 2160, 8, "exact"):
-        return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_balls4k_depth8_exact_serial.json")))
+    collected inside this run): (the newest such file's contents, its path relative to the
+    repository), or (None, None) when no profile of this workload is committed."""
+    tag = workload_tag(args)
+    files = []
+    for t in (tag, OLD_TAGS.get(tag)):
+        if t:
+            files += glob.glob(os.path.join(ROOT, "profiles", "r*", f"traffic_{t}_serial.json"))
+    files.sort(key=lambda f: (os.path.basename(os.path.dirname(f)), f))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -110,6 +124,9 @@ def parse_args():
                     help="timed frames one at a time on the serial schedule (one stream, one shadow launch): what the "
                          "per-kernel profiles under profiles/ are taken with")
     ap.add_argument("--shadow-mode", type=int, default=0, help="rt_options.shadow_mode: 0 closest hit (reference), 1 exact stop, 2 any hit (not parity)")
+    ap.add_argument("--orbit", action="store_true",
+                    help="after the timed region, the same number of steps again with the camera moving round the scene "
+                         "(frame_ms.orbit_step_wall): grid hints and pool sizes are then the previous view's, not this one's")
     ap.add_argument("--force-tiles", action="store_true",
                     help="one rank, but through the tile buffer, the RCCL gather and the de-interleave of a multi-GPU run")
     return ap.parse_args()
@@ -217,6 +234,51 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = stats[-1]
+    workspace_bytes = int(sum(s.workspace_bytes for s in stats[-in_flight[0]:]))  # the slots in use, each with pools of its own
+    # ---- the same steps with a moving camera: one turn round the view's `at` point about its `up` axis,
+    # a step at a time.  Every frame then differs from the one whose level sizes the library sized its
+    # grids and pools by; frames the pools do not hold are run again (retries).  Never `value`.
+    orbit = None
+    if args.orbit:
+        v0 = scene.view(W, H)
+        frm, at, up = (np.array(list(x), dtype=np.float64) for x in (v0.from_, v0.at, v0.up))
+        axis = up / np.linalg.norm(up)
+        arm = frm - at
+        views = []
+        for k in range(args.steps):
+            a = 2.0 * np.pi * (k + 1) / args.steps
+            r = arm * np.cos(a) + np.cross(axis, arm) * np.sin(a) + axis * np.dot(axis, arm) * (1.0 - np.cos(a))
+            views.append(scene.view(W, H, from_=tuple(at + r)))
+        o_stats = []
+
+        def orbit_step(v):
+            if len(pending) >= in_flight[0]:
+                o_stats.append(scene.render_device_end(pending.pop(0)))
+            target = mine if tiled else image
+            pending.append(scene.render_device_begin(opt, None, target.data_ptr(), stream, view=v))
+            if tiled:
+                tg.gather(stream)
+
+        fence()
+        t0 = time.perf_counter()
+        for v in views:
+            orbit_step(v)
+        while pending:
+            o_stats.append(scene.render_device_end(pending.pop(0)))
+        fence()
+        o_elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        o_rays = torch.tensor([float(sum(s.rays_total for s in o_stats))], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(o_elapsed, op=dist.ReduceOp.MAX)
+            dist.all_reduce(o_rays, op=dist.ReduceOp.SUM)
+        orbit = {"step_wall": float(o_elapsed.item()) / args.steps * 1e3, "retries": int(sum(s.retries for s in o_stats)),
+                 "rays_per_frame_mean": float(o_rays.item()) / args.steps,
+                 "mrays_per_s": float(o_rays.item()) / float(o_elapsed.item()) / 1e6}
+        # (back to the fixed view for what follows)
+        scene.render_device(opt, None, (mine if tiled else image).data_ptr(), stream)
+        if tiled:
+            tg.gather(stream)
+        torch.cuda.synchronize()
     local = torch.tensor([elapsed, float(st.rays_total), float(st.rays_primary), float(st.rays_shadow),
                           float(st.rays_reflect), float(st.rays_refract),
                           float(np.mean([s.ms_trace for s in stats])), float(np.mean([s.ms_resolve for s in stats])),
@@ -288,6 +350,10 @@ def main():
         return
 
     traffic, traffic_file = measured_traffic(args)
+    headline = (args.scene, args.size, W, H) == ("balls", 4, 3840, 2160)
+    # the kernel instances the library launched for this scene (rt_stats of the serial-schedule frames)
+    k_shadow_name = f"k_shadow<{serial[-1].kernel_shadow}, NoCounters>"
+    k_deep_name = f"k_intersect<false, {serial[-1].kernel_deep}, NoCounters>"
     def flops_of(w):
         return sum(w.get(k, 0.0) * (c - FLOP_SAVED.get(k, 0)) for k, c in FLOP.items())
     flops = flops_of(work)
@@ -309,7 +375,8 @@ def main():
     frame_s = kernel_ms["ms_frame"] * 1e-3
 
     out = {
-        "metric": "Mrays/s (all ray types), SPD balls @3840x2160",
+        "metric": ("Mrays/s (all ray types), SPD balls @3840x2160" if headline
+                   else f"Mrays/s (all ray types), SPD-style {args.scene} size {args.size} @{W}x{H}"),
         "value": round(value, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -333,6 +400,7 @@ def main():
             "rays_per_frame": {"primary": int(sm[2]), "shadow": int(sm[3]), "reflect": int(sm[4]),
                                "refract": int(sm[5]), "total": int(rays_frame)},
             "setup_s": round(setup_s, 3), "tree_build_ms": round(ti.build_ms, 1),
+            "workspace_bytes": workspace_bytes,  # ray pools and shadow queues of the frame slots in use
         },
         # step_wall: the timed region / steps (frames overlap when several are in flight); single_frame: one
         # frame at a time, image left in HBM (median wall time of rt_render_device); single_frame_host:
@@ -341,12 +409,15 @@ def main():
         "frame_ms": {"step_wall": round(ms_per_step, 4), "single_frame": round(single_ms, 4),
                      "single_frame_host": round(host_ms, 4) if host_ms is not None else None,
                      "device_frame": round(float(mx[8]), 4), "frames_in_flight": in_flight[0],
-                     "kernels_serial": {k: round(v, 4) for k, v in kernel_ms.items()}},
+                     "kernels_serial": {k: round(v, 4) for k, v in kernel_ms.items()},
+                     # (--orbit) the timed steps again with the camera going round the scene, a step at a time
+                     "orbit_step_wall": round(orbit["step_wall"], 4) if orbit else None,
+                     "orbit": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in orbit.items()} if orbit else None},
         "roofline": {
             # neither "hbm" nor "mfma" binds this path (no dense contraction; scene data is cache resident):
             # vector issue with few waves ready per SIMD does.  The HBM view is alongside.
             "bound": "valu",
-            "kernel": "k_shadow<6, NoCounters> (lean build of the shadow kernel; <2, NoCounters> on scenes with cones or polygon records)",
+            "kernel": k_shadow_name + " (CULL: 2 = culled walk, + 4 lean build, + 8 resident blocks, + 16 nodes in LDS); deeper levels: " + k_deep_name,
             "achieved": round(sh_flops / sh_s / 1e12, 4),
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",

@@ -184,6 +184,11 @@ typedef struct rt_stats {
     double ms_intersect_deep; /* the same for all deeper bounce levels */
     double ms_shadow;         /* k_shadow, all levels in one launch */
     double ms_light;          /* k_light */
+    /* which instances of the trace kernels the frame ran: the value of their CULL template argument
+     * (0 exhaustive, 1 / 2 culled walk, + 4 lean build, + 8 resident blocks, + 16 nodes in LDS); -1 = none */
+    int32_t kernel_shadow;    /* k_shadow<kernel_shadow, ...> */
+    int32_t kernel_deep;      /* k_intersect<false, kernel_deep, ...> of the levels below the camera rays */
+    uint64_t workspace_bytes; /* device memory the frame's slot holds for ray pools and shadow queues */
 } rt_stats;
 
 typedef struct rt_tree_info {
@@ -197,13 +202,19 @@ typedef struct rt_scene rt_scene;
 /* ---- lifetime ---- */
 /* n_devices >= 1 device ordinals (NULL = 0, 1, ...); the first is the root device, where whole
  * images are put together and where device output pointers must live.  A context over several
- * devices serves rt_scene_create, rt_render and rt_render_device (with tile_count <= 1: it does
- * the tiling itself); the frame-after-frame, static-workspace and diagnostic entry points, and
- * collect_work, are for one-device contexts.  *out is set even on failure, so that
+ * devices serves rt_scene_create, rt_render, rt_render_device and rt_render_device_begin / _end
+ * (with tile_count <= 1: it does the tiling itself; every rank's tiles travel to the root device
+ * by hipMemcpyPeerAsync, not by a collective); the static-workspace and diagnostic entry points,
+ * and collect_work, are for one-device contexts.  *out is set even on failure, so that
  * rt_last_error can be read; destroy it afterwards. */
 int rt_context_create(int n_devices, const int* device_ids, rt_context** out);
 /* Devices the context renders on. */
 uint32_t rt_context_device_count(const rt_context* ctx);
+/* How rank `rank`'s tiles reach the root device (no reference counterpart): 1 = directly (peer access
+ * enabled when the context was created, or the same device), 0 = staged by the runtime (the device
+ * cannot reach the root's memory, or enabling it failed); < 0 = bad argument.  *note_out (may be
+ * NULL) = what the runtime answered, valid while the context lives. */
+int rt_context_peer_access(const rt_context* ctx, uint32_t rank, const char** note_out);
 void rt_context_destroy(rt_context* ctx);
 const char* rt_last_error(const rt_context* ctx);
 
@@ -250,7 +261,7 @@ int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view
  * with larger pools.  rt_render_device_begin itself waits for, and re-runs, any frame that is
  * not like the last finished one (another scene, image share or depth, or the context's first),
  * so the promise above holds for it; every slot's pools are then kept at the largest size any
- * finished frame needed plus a quarter.  A later frame of the same kind whose rays outgrow even
+ * finished frame of that kind needed plus a quarter.  A later frame of the same kind whose rays outgrow even
  * that (a camera move that brings a quarter more rays than any frame before) is only re-run by
  * rt_render_device_end: rt_stats.retries > 0 then says that work queued on `stream` between
  * begin and end found the buffers as they were before this frame, that they hold the frame
@@ -267,9 +278,10 @@ uint32_t rt_frames_in_flight(const rt_context* ctx);
  * the reference, whose recursion keeps one ray at a time on the stack. */
 int rt_context_set_workspace_limit(rt_context* ctx, uint64_t bytes_per_frame_slot);
 
-/* rt_render_device for callers that cannot allocate device memory at the time of the call: code
- * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
- * counterpart in the reference.  Same arguments, same image, same statistics; but the frame's
+/* rt_render_device for callers that cannot allocate device memory at the time of the call: tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  It
+ * blocks until the frame is complete (it waits for events on streams of its own and reads pinned
+ * counters on the host), so it cannot be recorded under HIP stream capture.  Same arguments, same image, same statistics; but the frame's
  * ray pools, shadow queues and counters live in a static device array of
  * RT_STATIC_WORKSPACE_BYTES that each GPU the library runs on holds from load to exit, and the
  * call allocates and frees nothing (streams, events and pinned counters were made by

@@ -198,6 +198,9 @@ pub struct rt_stats {
     pub ms_intersect_deep: f64,
     pub ms_shadow: f64,
     pub ms_light: f64,
+    pub kernel_shadow: i32,
+    pub kernel_deep: i32,
+    pub workspace_bytes: u64,
 }
 
 #[repr(C)]
@@ -232,6 +235,7 @@ extern "C" {
     // ---- lifetime
     pub fn rt_context_create(n_devices: c_int, device_ids: *const c_int, out: *mut *mut rt_context) -> c_int;
     pub fn rt_context_device_count(ctx: *const rt_context) -> u32;
+    pub fn rt_context_peer_access(ctx: *const rt_context, rank: u32, note_out: *mut *const c_char) -> c_int;
     pub fn rt_context_destroy(ctx: *mut rt_context);
     pub fn rt_last_error(ctx: *const rt_context) -> *const c_char;
     pub fn rt_scene_create(ctx: *mut rt_context, desc: *const rt_scene_desc, out: *mut *mut rt_scene) -> c_int;

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
     "rt_debug_bound", "rt_frames_in_flight", "rt_context_set_workspace_limit", "rt_render_device_static", "rt_context_device_count",
+    "rt_context_peer_access",
 )
 
 
@@ -124,7 +125,8 @@ class rt_stats(C.Structure):
                 ("levels", C.c_uint32), ("retries", C.c_uint32), ("ms_trace", C.c_double), ("ms_resolve", C.c_double),
                 ("ms_frame", C.c_double), ("ms_d2h", C.c_double), ("work_shadow", C.c_uint64 * 16),
                 ("ms_intersect0", C.c_double), ("ms_intersect_deep", C.c_double), ("ms_shadow", C.c_double),
-                ("ms_light", C.c_double)]
+                ("ms_light", C.c_double), ("kernel_shadow", C.c_int32), ("kernel_deep", C.c_int32),
+                ("workspace_bytes", C.c_uint64)]
 
     @property
     def rays_total(self):
@@ -214,6 +216,7 @@ def lib():
     L.rt_context_set_workspace_limit.argtypes = [vp, C.c_uint64]
     L.rt_context_device_count.argtypes = [vp]
     L.rt_context_device_count.restype = C.c_uint32
+    L.rt_context_peer_access.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p)]
     L.rt_debug_intersect.argtypes = [vp, vp, C.c_uint32, C.c_uint64] + [vp] * 7
     L.rt_debug_eval.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
     _lib = L
@@ -329,6 +332,14 @@ class Context:
     def frames_in_flight(self) -> int:
         """How many frames render_device_begin may have queued at once."""
         return int(lib().rt_frames_in_flight(self._h))
+
+    def peer_access(self, rank: int):
+        """(1 direct / 0 staged by the runtime, what the runtime answered) for rank's copies to the root device."""
+        note = C.c_char_p()
+        rc = lib().rt_context_peer_access(self._h, rank, C.byref(note))
+        if rc < 0:
+            raise RtError(rc, "bad rank")
+        return rc, (note.value or b"").decode()
 
     def set_workspace_limit(self, bytes_per_frame_slot: int):
         """Bound on the ray pools one frame slot may hold (0 = none); frames needing more raise RT_ERR_CAPACITY."""

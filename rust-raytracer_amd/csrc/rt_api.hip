@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -100,6 +101,7 @@ struct FrameSlot {
     unsigned long long* h_counters = nullptr;        // itself (a blocking copy would wait for the other frame too)
     // the frame in flight
     bool busy = false;
+    bool unsettled = false;   // queued with pools of unproven size and not waited for yet (settle_frame)
     bool finished = false;    // waited for and its statistics kept in `stats` already (rt_render_device_begin did)
     int finish_rc = 0;
     rt_stats stats{};
@@ -110,6 +112,18 @@ struct FrameSlot {
     void* out_f32 = nullptr;
     void* out_u8 = nullptr;
     hipStream_t caller = nullptr;
+    int variant_deep = -1, variant_shadow = -1;  // CULL values of the kernel instances this frame launched
+    // A context over several devices: the frame of ticket t uses slot t of every rank's context.  Each
+    // rank's slot has its own compact tile buffers (the root's: the gathered buffers), the stream its
+    // share of the frame ends on and its copy to the root runs on, and the event that ends both.
+    DevBuf<float> tile_f32, gathered_f32;
+    DevBuf<uint8_t> tile_u8, gathered_u8;
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t ev_gather = nullptr;
+    bool multi = false;        // the root's slot: a frame over all the context's devices is in flight under this ticket
+    void* multi_f32 = nullptr; // ... into these images of the caller's, on this stream of the caller's
+    void* multi_u8 = nullptr;
+    hipStream_t multi_stream = nullptr;
 };
 
 constexpr uint32_t RT_MAX_FRAME_SLOTS = 4;
@@ -124,14 +138,16 @@ struct rt_context {
     // together) plus one one-device context per further rank.  Every rank keeps its own compact
     // tile buffers, a stream for its frame and the copy to the root, and the event that ends both.
     std::vector<rt_context*> peers;
-    DevBuf<float> tile_f32, gathered_f32;
-    DevBuf<uint8_t> tile_u8, gathered_u8;
-    hipStream_t gather_stream = nullptr;
-    hipEvent_t ev_gather = nullptr;
+    // per further rank: 1 = its device reaches the root's memory directly (peer access enabled, or the same
+    // device), 0 = it does not and the runtime stages the copies; and what the runtime said
+    std::vector<int> peer_direct;
+    std::vector<std::string> peer_note;
     FrameSlot fixed_slot;                // rt_render_device_static: its workspace is a share of `scratch`
     unsigned char* scratch_ptr = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress)
-    // Pool sizes every slot is brought to before a frame: the largest any finished frame needed,
-    // with headroom, so that a slot's first frame does not overflow where another's already has.
+    // Pool sizes every slot is brought to before a frame LIKE the finished ones they come from (same
+    // scene, image share and depth: the hint's key below): the largest any of those needed, with
+    // headroom, so that a slot's first frame does not overflow where another's already has.  Frames of
+    // another kind start from their own floor and reset these.
     size_t want_pool = 0, want_shadow1 = 0;
     uint64_t workspace_limit = 0;        // bytes of pools per frame slot the caller allows; 0 = no limit
     DevBuf<float> out_f32;
@@ -139,13 +155,16 @@ struct rt_context {
     bool kernels_ready = false;
     // Sizes of the last finished frame's levels: how many blocks the next frame of the same scene and
     // size launches per level.  Only a hint -- every kernel strides over its level whatever the grid.
-    const rt_scene* hint_scene = nullptr;
+    uint64_t hint_scene = 0;  // rt_scene::serial (a number, not an address: a scene created where a destroyed one lay is another scene)
     uint32_t hint_slots = 0, hint_depth = 0;
     uint32_t hint_rays[RT_MAX_LEVELS] = {}, hint_lit[RT_MAX_LEVELS] = {};
 };
 
+static std::atomic<uint64_t> g_scene_serial{0};
+
 struct rt_scene {
     rt_context* ctx = nullptr;
+    uint64_t serial = ++g_scene_serial;  // never 0, never reused
     std::vector<rt_scene*> peer_scenes;  // the copies on the context's further devices
     ~rt_scene() {
         for (rt_scene* p : peer_scenes) delete p;
@@ -270,6 +289,8 @@ int setup_slot(rt_context* ctx, FrameSlot& f) {
     RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_shadow, hipEventDisableTiming));
     RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_caller, hipEventDisableTiming));
     RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
+    RT_HIP(ctx, hipStreamCreateWithFlags(&f.gather_stream, hipStreamNonBlocking));
+    RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_gather, hipEventDisableTiming));
     for (auto& e : f.ev_t) RT_HIP(ctx, hipEventCreate(&e));
     RT_HIP(ctx, hipHostMalloc((void**)&f.h_levels, LV_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     RT_HIP(ctx, hipHostMalloc((void**)&f.h_counters, N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault));
@@ -285,6 +306,8 @@ void teardown_slot(FrameSlot& f) {
     if (f.ev_shadow) (void)hipEventDestroy(f.ev_shadow);
     if (f.ev_caller) (void)hipEventDestroy(f.ev_caller);
     if (f.ev_done) (void)hipEventDestroy(f.ev_done);
+    if (f.ev_gather) (void)hipEventDestroy(f.ev_gather);
+    if (f.gather_stream) (void)hipStreamDestroy(f.gather_stream);
     for (auto& e : f.ev_t)
         if (e) (void)hipEventDestroy(e);
     if (f.h_levels) (void)hipHostFree(f.h_levels);
@@ -338,8 +361,6 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         int rc = prepare_kernels(ctx);
         if (rc != RT_OK) return rc;
     }
-    RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
-    RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gather, hipEventDisableTiming));
     // further devices: one one-device context each; their tile buffers are copied into this device
     for (int r = 1; r < n_devices; ++r) {
         const int id = device_ids ? device_ids[r] : r;
@@ -347,14 +368,25 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         const int rc = rt_context_create(1, &id, &peer);
         if (peer) ctx->peers.push_back(peer);
         if (rc != RT_OK) return fail(ctx, rc, std::string("device ") + std::to_string(id) + ": " + (peer ? peer->err : "no context"));
-        if (id != ctx->device) {  // direct copies over the GPUs' links where the platform allows them
+        // Direct copies over the GPUs' links where the platform allows them; what the runtime answered is
+        // kept (rt_context_peer_access): without peer access the copies still work, staged by the runtime.
+        int direct = 1;
+        std::string note = "same device";
+        if (id != ctx->device) {
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, id, ctx->device) == hipSuccess && can) {
-                (void)hipSetDevice(id);
-                (void)hipDeviceEnablePeerAccess(ctx->device, 0);
-                (void)hipGetLastError();  // (already enabled is not an error here)
+            hipError_t e = hipDeviceCanAccessPeer(&can, id, ctx->device);
+            if (e == hipSuccess && can) {
+                e = hipSetDevice(id);
+                if (e == hipSuccess) e = hipDeviceEnablePeerAccess(ctx->device, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
             }
+            (void)hipGetLastError();
+            direct = (e == hipSuccess && can) ? 1 : 0;
+            note = e != hipSuccess ? std::string("peer access refused: ") + hipGetErrorString(e)
+                                   : (can ? "peer access enabled" : "the device cannot reach the root's memory: copies are staged");
         }
+        ctx->peer_direct.push_back(direct);
+        ctx->peer_note.push_back(note);
     }
     RT_HIP(ctx, hipSetDevice(ctx->device));
     return RT_OK;
@@ -362,14 +394,18 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
 
 extern "C" uint32_t rt_context_device_count(const rt_context* ctx) { return ctx ? 1u + (uint32_t)ctx->peers.size() : 0u; }
 
+extern "C" int rt_context_peer_access(const rt_context* ctx, uint32_t rank, const char** note_out) {
+    if (!ctx || rank > ctx->peers.size()) return RT_ERR_INVALID;
+    if (note_out) *note_out = rank == 0 ? "the root device" : ctx->peer_note[rank - 1].c_str();
+    return rank == 0 ? 1 : ctx->peer_direct[rank - 1];
+}
+
 extern "C" void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
     for (rt_context* p : ctx->peers) rt_context_destroy(p);
     (void)hipSetDevice(ctx->device);
     for (FrameSlot& f : ctx->slot) teardown_slot(f);
     teardown_slot(ctx->fixed_slot);
-    if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
-    if (ctx->gather_stream) (void)hipStreamDestroy(ctx->gather_stream);
     delete ctx;
 }
 
@@ -695,6 +731,17 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     if (cap > 0xf0000000ull || scap * p.lights1 > 0xf0000000ull)
         return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
     if (!f.fixed && ctx->workspace_limit != 0 &&
+        (uint64_t)cap * NODE_BYTES + (uint64_t)scap * p.lights1 * SHADOW_BYTES <= ctx->workspace_limit &&
+        (uint64_t)f.ws.pool_cap * NODE_BYTES + (uint64_t)f.ws.shadow_cap * SHADOW_BYTES > ctx->workspace_limit) {
+        // The slot holds more than the limit allows -- pools grown for an earlier, larger frame, before
+        // the limit was lowered -- and this frame fits it: the pools are given back and made anew.
+        f.ray_o.release(); f.ray_d.release(); f.node_col.release(); f.node_kid.release();
+        f.hit_a.release(); f.hit_p.release(); f.node_sh.release();
+        f.sray_o.release(); f.sray_d.release(); f.sray_blocked.release();
+        f.ws.pool_cap = 0;
+        f.ws.shadow_cap = 0;
+    }
+    if (!f.fixed && ctx->workspace_limit != 0 &&
         (uint64_t)std::max(cap, f.ws.pool_cap) * NODE_BYTES + (uint64_t)std::max(scap * p.lights1, f.ws.shadow_cap) * SHADOW_BYTES >
             ctx->workspace_limit)
         return fail(ctx, RT_ERR_CAPACITY,
@@ -781,6 +828,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     const bool one_stream = f.one_stream || serial;
     hipStream_t st = f.main_stream, st2 = one_stream ? f.main_stream : f.shadow_stream;
     f.timed_levels = 0;
+    f.variant_deep = f.variant_shadow = -1;
     // What the caller's stream holds now comes before this attempt's writes to the caller's buffers.
     // (A re-run from rt_render_device_end records it afresh: frames begun in the meantime into the
     // same buffers, and whatever consumes them, are on that stream by then.)
@@ -798,7 +846,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // rays need (a quarter more, at least one block per CU) instead of the most it could need:
     // the blocks past a level's end only start, read the level's size and leave, but there are
     // tens of thousands of them per launch and they hold wave slots while they do.
-    const bool hinted = ctx->hint_scene == scene && ctx->hint_slots == n_slots && ctx->hint_depth == opt->max_depth;
+    const bool hinted = ctx->hint_scene == scene->serial && ctx->hint_slots == n_slots && ctx->hint_depth == opt->max_depth;
     auto blocks_for = [&](uint64_t rays, uint32_t most) -> uint32_t {
         if (!hinted) return most;
         const uint64_t b = (rays + (rays >> 2) + RT_BLOCK - 1) / RT_BLOCK;
@@ -809,14 +857,15 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         for (uint32_t l = first; l <= last; ++l) lit += ctx->hint_lit[l];
         const uint32_t gs = blocks_for(lit, first == 0 ? grids : gridn);
         RT_HIP(ctx, hipStreamWaitEvent(st2, f.ev_level[last], 0));
-        RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2)
-                         : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2));
+        RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2, &f.variant_shadow)
+                         : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2, &f.variant_shadow));
         return RT_OK;
     };
     bool lit_level0 = false;  // level 0's lighting is queued already
     for (uint32_t level = 0; level <= last_level; ++level) {
         const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
-        RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st) : rt_exact::launch_intersect(A, level, work, cull, g, st));
+        int* variant = level > 0 ? &f.variant_deep : nullptr;
+        RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st, variant) : rt_exact::launch_intersect(A, level, work, cull, g, st, variant));
         if (serial) {
             RT_HIP(ctx, hipEventRecord(f.ev_t[level], st));
             f.timed_levels = level + 1;
@@ -908,7 +957,10 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
             if (rc != RT_OK) return rc;
             continue;
         }
-        // what the next frames' pools should hold, on every slot: this frame's need and a quarter more
+        // what the next frames of this kind should find in their pools, on every slot: this frame's need and
+        // a quarter more (the largest over the finished frames of the kind; another kind starts afresh)
+        if (ctx->hint_scene != f.scene->serial || ctx->hint_slots != p.n_slots || ctx->hint_depth != opt->max_depth)
+            ctx->want_pool = ctx->want_shadow1 = 0;
         ctx->want_pool = std::max<size_t>(ctx->want_pool, (size_t)need + (need >> 2));
         ctx->want_shadow1 = std::max<size_t>(ctx->want_shadow1, (size_t)sneed + (sneed >> 2));
         unsigned long long c[N_COUNTERS];
@@ -922,13 +974,16 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
             stats.work[k] = c[4 + k] + c[24 + k];
             stats.work_shadow[k] = c[24 + k];
         }
-        ctx->hint_scene = f.scene;
+        ctx->hint_scene = f.scene->serial;
         ctx->hint_slots = p.n_slots;
         ctx->hint_depth = opt->max_depth;
         for (uint32_t l = 0; l < RT_MAX_LEVELS; ++l) {
             ctx->hint_rays[l] = l <= opt->max_depth ? lv[l] : 0u;
             ctx->hint_lit[l] = l <= opt->max_depth ? lv[LV_SHADOW_COUNT + l] : 0u;
         }
+        stats.kernel_shadow = f.variant_shadow;
+        stats.kernel_deep = f.variant_deep;
+        stats.workspace_bytes = (uint64_t)f.ws.pool_cap * NODE_BYTES + (uint64_t)f.ws.shadow_cap * SHADOW_BYTES;
         stats.ray_nodes = p.n_slots;
         stats.levels = 1;
         for (uint32_t l = 1; l <= opt->max_depth; ++l) {
@@ -982,16 +1037,44 @@ int check_frame_args(rt_context* ctx, const rt_scene* scene, const rt_view* view
 
 namespace {
 
+// A frame of unproven size, queued by begin_frame: waited for and re-run until its pools hold it.
+int settle_frame(rt_context* ctx, uint32_t id) {
+    FrameSlot& f = ctx->slot[id];
+    if (!f.busy || !f.unsettled) return RT_OK;
+    f.unsettled = false;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    f.finish_rc = finish_frame(ctx, f, &f.stats);
+    f.finished = true;
+    if (f.finish_rc != RT_OK) f.busy = false;
+    return f.finish_rc;
+}
+
+// Ends the frame of slot `id` whatever its state (error paths of a frame over several devices).
+int begin_end_quietly(rt_context* ctx, uint32_t id) {
+    FrameSlot& f = ctx->slot[id];
+    if (!f.busy) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    int rc = RT_OK;
+    if (!f.finished) rc = finish_frame(ctx, f, nullptr);
+    f.busy = false;
+    f.unsettled = false;
+    return rc;
+}
+
 // (rt_render_device_begin, also for one rank of a context over several devices)
+// slot < 0: the context's next slot, which then moves on; else that slot (a rank of a context over several
+// devices follows the root's ticket).  settle_now false: a frame of unproven size is only queued, and the
+// caller settles it (settle_frame) once it has queued the other ranks' frames as well.
 int begin_frame(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
-                                      void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out) {
+                                      void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out,
+                                      int slot = -1, bool settle_now = true) {
     if (!ticket_out) return fail(ctx, RT_ERR_INVALID, "null argument");
     int rc = check_frame_args(ctx, scene, view, opt);
     if (rc != RT_OK) return rc;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     rc = prepare_kernels(ctx);
     if (rc != RT_OK) return rc;
-    const uint32_t id = ctx->next_slot;
+    const uint32_t id = slot < 0 ? ctx->next_slot : (uint32_t)slot;
     FrameSlot& f = ctx->slot[id];
     if (f.busy) return fail(ctx, RT_ERR_INVALID, "every frame slot is in flight already: call rt_render_device_end first");
     {
@@ -1011,41 +1094,45 @@ int begin_frame(rt_context* ctx, const rt_scene* scene, const rt_view* view, con
     // Pools: what this slot has, what finished frames on any slot needed (and a quarter more), and
     // room for the camera rays and as many again.  Shadow queues hold the whole frame's lit hits,
     // times the number of lights.
-    const size_t floor_cap = std::max<size_t>((size_t)p.n_slots * 2, 1u << 16);
-    const size_t cap = std::max(std::max(f.ws.pool_cap, ctx->want_pool), floor_cap);
-    const size_t scap = std::max(std::max(f.ws.shadow_cap / p.lights1, ctx->want_shadow1), floor_cap);
     // A frame like the last finished one (same scene, image share and depth) is known to fit pools of
-    // that size, or to come close.  Any other frame is waited for here, pools grown and the frame
-    // re-run as often as it takes, so that what the caller queues on `stream` after this call finds
-    // the finished image.
-    const bool proven = ctx->hint_scene == scene && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth;
+    // that size, or to come close.
+    const bool proven = ctx->hint_scene == scene->serial && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth;
+    const size_t floor_cap = std::max<size_t>((size_t)p.n_slots * 2, 1u << 16);
+    const size_t cap = std::max(std::max(f.ws.pool_cap, proven ? ctx->want_pool : 0), floor_cap);
+    const size_t scap = std::max(std::max(f.ws.shadow_cap / p.lights1, proven ? ctx->want_shadow1 : 0), floor_cap);
+    // Any other frame is waited for here, pools grown and the frame re-run as often as it takes, so that
+    // what the caller queues on `stream` after this call finds the finished image.
     rc = enqueue_frame(ctx, f, p, cap, scap);
     if (rc != RT_OK) return rc;
     f.busy = true;
     f.finished = false;
-    if (!proven) {
-        f.finish_rc = finish_frame(ctx, f, &f.stats);
-        f.finished = true;
-        if (f.finish_rc != RT_OK) {
-            f.busy = false;
-            return f.finish_rc;
-        }
+    f.unsettled = !proven;
+    if (settle_now) {
+        rc = settle_frame(ctx, id);
+        if (rc != RT_OK) return rc;
     }
-    ctx->next_slot = (id + 1u) % ctx->n_slots;
+    if (slot < 0) ctx->next_slot = (id + 1u) % ctx->n_slots;
     *ticket_out = id;
     return RT_OK;
 }
 
 }  // namespace
 
+namespace {
+int multi_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt, void* d_f32, void* d_u8,
+                void* stream, uint32_t* ticket_out);
+int multi_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out);
+}  // namespace
+
 extern "C" int rt_render_device_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                                       void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, uint32_t* ticket_out) {
-    if (ctx && !ctx->peers.empty()) return fail(ctx, RT_ERR_UNSUPPORTED, "frames in flight are for one-device contexts");
+    if (ctx && !ctx->peers.empty()) return multi_begin(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, ticket_out);
     return begin_frame(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, ticket_out);
 }
 
 extern "C" int rt_render_device_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out) {
     if (!ctx || ticket >= ctx->n_slots) return fail(ctx, RT_ERR_INVALID, "bad ticket");
+    if (!ctx->peers.empty()) return multi_end(ctx, ticket, stats_out);
     FrameSlot& f = ctx->slot[ticket];
     if (!f.busy) return fail(ctx, RT_ERR_INVALID, "no frame in flight under this ticket");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1130,98 +1217,159 @@ extern "C" uint32_t rt_frames_in_flight(const rt_context* ctx) { return ctx ? ct
 
 namespace {
 
-// One frame on a context over several devices: every rank (device) traces its interleaved 8x8
-// tiles into a compact buffer (pixels are independent, src/render.rs:104-112; every device holds
-// the whole scene), ranks 1.. copy theirs into the root device's gathered buffer over the GPUs'
-// links, and the root de-interleaves into the caller's image.  All ranks' frames are queued
-// before any is waited for.
-int render_multi(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt, void* d_f32, void* d_u8,
-                 void* stream, rt_stats* stats_out) {
+// A frame on a context over several devices: every rank (device) traces its interleaved 8x8 tiles into
+// a compact buffer (pixels are independent, src/render.rs:104-112; every device holds the whole scene),
+// ranks 1.. copy theirs into the root device's gathered buffer (hipMemcpyPeerAsync on the rank's own
+// stream: over the GPUs' links where peer access is enabled, rt_context_peer_access), and the root
+// de-interleaves into the caller's image on the caller's stream.  The frame of ticket t uses slot t of
+// every rank's context, with tile and gathered buffers of its own, so up to rt_frames_in_flight frames
+// may be queued.  Every rank's share is queued before any is waited for.
+int multi_begin(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt, void* d_f32, void* d_u8,
+                void* stream, uint32_t* ticket_out) {
+    if (!ticket_out) return fail(ctx, RT_ERR_INVALID, "null argument");
     int rc = check_frame_args(ctx, scene, view, opt);
     if (rc != RT_OK) return rc;
     const uint32_t n = 1u + (uint32_t)ctx->peers.size();
     if ((opt->tile_count > 1) || opt->compact_tiles || opt->collect_work)
         return fail(ctx, RT_ERR_UNSUPPORTED, "a context over several devices tiles the image itself and keeps no work counters");
     if (scene->peer_scenes.size() + 1 != n) return fail(ctx, RT_ERR_INVALID, "scene was not created on this context");
+    const uint32_t id = ctx->next_slot;
+    auto rank_ctx = [&](uint32_t r) { return r == 0 ? ctx : ctx->peers[r - 1]; };
+    for (uint32_t r = 0; r < n; ++r)
+        if (rank_ctx(r)->slot[id].busy)
+            return fail(ctx, RT_ERR_INVALID, "every frame slot is in flight already: call rt_render_device_end first");
     const uint32_t W = view->width, H = view->height;
     const size_t stride = (size_t)rt_tile_pixels_max(W, H, n);
     RT_HIP(ctx, hipSetDevice(ctx->device));
-    if (d_f32 && ctx->gathered_f32.n < stride * n * 3) RT_HIP(ctx, ctx->gathered_f32.alloc(stride * n * 3));
-    if (d_u8 && ctx->gathered_u8.n < stride * n * 3) RT_HIP(ctx, ctx->gathered_u8.alloc(stride * n * 3));
-    uint32_t ticket[MAX_DEVICES];
+    FrameSlot& root = ctx->slot[id];
+    if (d_f32 && root.gathered_f32.n < stride * n * 3) RT_HIP(ctx, root.gathered_f32.alloc(stride * n * 3));
+    if (d_u8 && root.gathered_u8.n < stride * n * 3) RT_HIP(ctx, root.gathered_u8.alloc(stride * n * 3));
     uint32_t begun = 0;
-    auto rank_ctx = [&](uint32_t r) { return r == 0 ? ctx : ctx->peers[r - 1]; };
     std::string err;
+    // 1. every rank's share on its own device's streams; nothing is waited for
     for (uint32_t r = 0; r < n && rc == RT_OK; ++r) {
         rt_context* c = rank_ctx(r);
+        FrameSlot& fs = c->slot[id];
         const rt_scene* sc = r == 0 ? scene : scene->peer_scenes[r - 1];
         hipError_t e = hipSetDevice(c->device);
-        const size_t mine = (size_t)rt_tile_pixels(W, H, r, n) * 3;
         float* pf = nullptr;
         uint8_t* pu = nullptr;
         if (r == 0) {  // the root's share goes straight into its place
-            pf = d_f32 ? ctx->gathered_f32.p : nullptr;
-            pu = d_u8 ? ctx->gathered_u8.p : nullptr;
+            pf = d_f32 ? root.gathered_f32.p : nullptr;
+            pu = d_u8 ? root.gathered_u8.p : nullptr;
         } else {
-            if (e == hipSuccess && d_f32 && c->tile_f32.n < stride * 3) e = c->tile_f32.alloc(stride * 3);
-            if (e == hipSuccess && d_u8 && c->tile_u8.n < stride * 3) e = c->tile_u8.alloc(stride * 3);
-            pf = d_f32 ? c->tile_f32.p : nullptr;
-            pu = d_u8 ? c->tile_u8.p : nullptr;
+            if (e == hipSuccess && d_f32 && fs.tile_f32.n < stride * 3) e = fs.tile_f32.alloc(stride * 3);
+            if (e == hipSuccess && d_u8 && fs.tile_u8.n < stride * 3) e = fs.tile_u8.alloc(stride * 3);
+            pf = d_f32 ? fs.tile_f32.p : nullptr;
+            pu = d_u8 ? fs.tile_u8.p : nullptr;
         }
         if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); break; }
         rt_options o = *opt;
         o.tile_rank = r;
         o.tile_count = n;
-        rc = begin_frame(c, sc, view, &o, pf, pu, c->gather_stream, &ticket[r]);
+        uint32_t t = 0;
+        rc = begin_frame(c, sc, view, &o, pf, pu, fs.gather_stream, &t, (int)id, false);
         if (rc != RT_OK) { err = "device " + std::to_string(c->device) + ": " + c->err; break; }
         ++begun;
+    }
+    // 2. shares of unproven size (the first frame of a scene, size or depth) are waited for and re-run
+    // until their pools hold them, now that every device has work
+    for (uint32_t r = 0; r < begun && rc == RT_OK; ++r) {
+        rt_context* c = rank_ctx(r);
+        rc = settle_frame(c, id);
+        if (rc != RT_OK) err = "device " + std::to_string(c->device) + ": " + c->err;
+    }
+    // 3. the copies to the root, each behind its rank's share (the share's last kernel is what the rank's
+    // stream waits for), and the event that ends share and copy
+    for (uint32_t r = 0; r < begun && rc == RT_OK; ++r) {
+        rt_context* c = rank_ctx(r);
+        FrameSlot& fs = c->slot[id];
+        hipError_t e = hipSetDevice(c->device);
+        const size_t mine = (size_t)rt_tile_pixels(W, H, r, n) * 3;
         if (r > 0) {
-            if (d_f32) e = hipMemcpyPeerAsync(ctx->gathered_f32.p + (size_t)r * stride * 3, ctx->device, pf, c->device,
-                                              mine * sizeof(float), c->gather_stream);
+            if (e == hipSuccess && d_f32)
+                e = hipMemcpyPeerAsync(root.gathered_f32.p + (size_t)r * stride * 3, ctx->device, fs.tile_f32.p, c->device,
+                                       mine * sizeof(float), fs.gather_stream);
             if (e == hipSuccess && d_u8)
-                e = hipMemcpyPeerAsync(ctx->gathered_u8.p + (size_t)r * stride * 3, ctx->device, pu, c->device, mine, c->gather_stream);
+                e = hipMemcpyPeerAsync(root.gathered_u8.p + (size_t)r * stride * 3, ctx->device, fs.tile_u8.p, c->device, mine, fs.gather_stream);
         }
-        if (e == hipSuccess) e = hipEventRecord(c->ev_gather, c->gather_stream);
+        if (e == hipSuccess) e = hipEventRecord(fs.ev_gather, fs.gather_stream);
         if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); }
     }
     (void)hipSetDevice(ctx->device);
+    // 4. the image, on the caller's stream, once every share has arrived
     if (rc == RT_OK) {
         hipError_t e = hipSuccess;
-        for (uint32_t r = 0; r < n && e == hipSuccess; ++r) e = hipStreamWaitEvent((hipStream_t)stream, rank_ctx(r)->ev_gather, 0);
+        for (uint32_t r = 0; r < n && e == hipSuccess; ++r) e = hipStreamWaitEvent((hipStream_t)stream, rank_ctx(r)->slot[id].ev_gather, 0);
         if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); }
-        if (rc == RT_OK && d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, ctx->gathered_f32.p, d_f32, stream);
-        if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, ctx->gathered_u8.p, d_u8, stream);
+        if (rc == RT_OK && d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, root.gathered_f32.p, d_f32, stream);
+        if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, root.gathered_u8.p, d_u8, stream);
         if (rc != RT_OK && err.empty()) err = ctx->err;
     }
-    // every frame that was begun is ended, whatever happened since
+    if (rc != RT_OK) {  // every share that was begun is ended, whatever happened since
+        for (uint32_t r = 0; r < begun; ++r) {
+            rt_context* c = rank_ctx(r);
+            if (c->slot[id].busy) (void)begin_end_quietly(c, id);
+        }
+        (void)hipSetDevice(ctx->device);
+        return fail(ctx, rc, err);
+    }
+    root.multi = true;
+    root.multi_f32 = d_f32;
+    root.multi_u8 = d_u8;
+    root.multi_stream = (hipStream_t)stream;
+    ctx->next_slot = (id + 1u) % ctx->n_slots;
+    *ticket_out = id;
+    return RT_OK;
+}
+
+int multi_end(rt_context* ctx, uint32_t ticket, rt_stats* stats_out) {
+    FrameSlot& root = ctx->slot[ticket];
+    if (!root.multi) return fail(ctx, RT_ERR_INVALID, "no frame in flight under this ticket");
+    root.multi = false;
+    const uint32_t n = 1u + (uint32_t)ctx->peers.size();
+    auto rank_ctx = [&](uint32_t r) { return r == 0 ? ctx : ctx->peers[r - 1]; };
+    const uint32_t W = root.view.width, H = root.view.height;
+    const size_t stride = (size_t)rt_tile_pixels_max(W, H, n);
+    void* d_f32 = root.multi_f32;
+    void* d_u8 = root.multi_u8;
+    hipStream_t stream = root.multi_stream;
+    int rc = RT_OK;
+    std::string err;
     rt_stats total;
     memset(&total, 0, sizeof(total));
-    for (uint32_t r = 0; r < begun; ++r) {
+    bool again = false;  // some share was run again after its copy had been queued
+    for (uint32_t r = 0; r < n; ++r) {
         rt_context* c = rank_ctx(r);
+        FrameSlot& fs = c->slot[ticket];
+        if (!fs.busy) continue;
+        (void)hipSetDevice(c->device);
         rt_stats st;
-        const int rc_end = rt_render_device_end(c, ticket[r], &st);
+        memset(&st, 0, sizeof(st));
+        int rc_end = RT_OK;
+        if (fs.finished) st = fs.stats;
+        else rc_end = finish_frame(c, fs, &st);
+        fs.busy = false;
         if (rc_end != RT_OK) {
             if (rc == RT_OK) { rc = rc_end; err = "device " + std::to_string(c->device) + ": " + c->err; }
             continue;
         }
-        if (st.retries > 0 && r > 0 && rc == RT_OK) {
-            // the frame was run again after its copy to the root had been queued: copy again
-            (void)hipSetDevice(c->device);
-            const size_t mine = (size_t)rt_tile_pixels(W, H, r, n) * 3;
-            hipError_t e = hipSuccess;
-            if (d_f32) e = hipMemcpyPeer(ctx->gathered_f32.p + (size_t)r * stride * 3, ctx->device, c->tile_f32.p, c->device, mine * sizeof(float));
-            if (e == hipSuccess && d_u8) e = hipMemcpyPeer(ctx->gathered_u8.p + (size_t)r * stride * 3, ctx->device, c->tile_u8.p, c->device, mine);
-            if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); }
-            (void)hipSetDevice(ctx->device);
-            if (rc == RT_OK && d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, ctx->gathered_f32.p, d_f32, stream);
-            if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, ctx->gathered_u8.p, d_u8, stream);
-        } else if (st.retries > 0 && r == 0 && rc == RT_OK) {
-            if (d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, ctx->gathered_f32.p, d_f32, stream);
-            if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, ctx->gathered_u8.p, d_u8, stream);
+        if (st.retries > 0 && !fs.finished) {
+            again = true;
+            if (r > 0 && rc == RT_OK) {  // (the re-run is complete: finish_frame waited for it)
+                const size_t mine = (size_t)rt_tile_pixels(W, H, r, n) * 3;
+                hipError_t e = hipSuccess;
+                if (d_f32) e = hipMemcpyPeer(root.gathered_f32.p + (size_t)r * stride * 3, ctx->device, fs.tile_f32.p, c->device, mine * sizeof(float));
+                if (e == hipSuccess && d_u8) e = hipMemcpyPeer(root.gathered_u8.p + (size_t)r * stride * 3, ctx->device, fs.tile_u8.p, c->device, mine);
+                if (e != hipSuccess) { rc = RT_ERR_DEVICE; err = hipGetErrorString(e); }
+            }
         }
         total.rays_primary += st.rays_primary; total.rays_shadow += st.rays_shadow;
         total.rays_reflect += st.rays_reflect; total.rays_refract += st.rays_refract;
         total.ray_nodes += st.ray_nodes;
+        total.workspace_bytes += st.workspace_bytes;
+        total.kernel_shadow = st.kernel_shadow;
+        total.kernel_deep = st.kernel_deep;
         total.levels = std::max(total.levels, st.levels);
         total.retries = std::max(total.retries, st.retries);
         total.ms_trace = std::max(total.ms_trace, st.ms_trace);
@@ -1229,8 +1377,12 @@ int render_multi(rt_context* ctx, const rt_scene* scene, const rt_view* view, co
         total.ms_frame = std::max(total.ms_frame, st.ms_frame);
     }
     (void)hipSetDevice(ctx->device);
+    if (rc == RT_OK && again) {  // the image once more, from the shares as they are now
+        if (d_f32) rc = rt_deinterleave_device(ctx, W, H, n, stride, 4, root.gathered_f32.p, d_f32, stream);
+        if (rc == RT_OK && d_u8) rc = rt_deinterleave_device(ctx, W, H, n, stride, 1, root.gathered_u8.p, d_u8, stream);
+        if (rc != RT_OK) err = ctx->err;
+    }
     if (rc != RT_OK) return fail(ctx, rc, err);
-    RT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     if (stats_out) *stats_out = total;
     return RT_OK;
 }
@@ -1239,11 +1391,13 @@ int render_multi(rt_context* ctx, const rt_scene* scene, const rt_view* view, co
 
 extern "C" int rt_render_device(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,
                                 void* d_rgb_f32_out, void* d_rgb_u8_out, void* stream, rt_stats* stats_out) {
-    if (ctx && !ctx->peers.empty()) return render_multi(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, stats_out);
     uint32_t ticket = 0;
     int rc = rt_render_device_begin(ctx, scene, view, opt, d_rgb_f32_out, d_rgb_u8_out, stream, &ticket);
     if (rc != RT_OK) return rc;
-    return rt_render_device_end(ctx, ticket, stats_out);
+    rc = rt_render_device_end(ctx, ticket, stats_out);
+    // (several devices: the image is put together by a kernel on `stream`, after the last share's copy)
+    if (rc == RT_OK && !ctx->peers.empty()) RT_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return rc;
 }
 
 extern "C" int rt_render(rt_context* ctx, const rt_scene* scene, const rt_view* view, const rt_options* opt,

@@ -897,7 +897,8 @@ hipError_t init_kernels() {
 }
 
 // `work` selects the instrumented kernels, `cull` the culled walk of big leaves.
-hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st) {
+// *variant (may be null): the CULL value of the kernel instance launched.
+hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant) {
     const bool lean = A.scene.lean != 0;
     const uint32_t which = level == 0 ? 0u : 1u;
     const bool gen_stays = !work && cull && !lean && A.scene.nodes_lds != 0u && level > 0 && RT_STAY_GEN_DEEP != 0;
@@ -905,6 +906,10 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
     const uint32_t tb = trace_block(A.scene, stays, which);
     const dim3 g(blocks_of(grid, tb, stays, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU)), b(tb);
     const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays);
+    if (variant) {
+        if (level == 0) *variant = !cull ? 0 : (!work && lean ? LEAN_I0 : 1);
+        else *variant = !cull ? 0 : (work ? 2 : (lean ? LEAN_ID : (gen_stays ? GEN_ID : 2)));
+    }
     if (level == 0) {  // camera rays start outside the scene: the line test alone
         if (work && cull) hipLaunchKernelGGL((k_intersect<true, 1, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<true, 0, WorkCounters>), g, b, lds, st, A, level);
@@ -923,7 +928,7 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 }
 
 hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, uint32_t grid,
-                         hipStream_t st) {
+                         hipStream_t st, int* variant) {
     const bool lean_kernel = !work && cull && A.scene.lean != 0;
     const uint32_t which = 2u + (A.shadow_mode <= 2u ? A.shadow_mode : 0u);
     const bool gen_stays = !work && cull && A.scene.lean == 0 && A.scene.nodes_lds != 0u && A.shadow_mode == 0u && RT_STAY_GEN_SHADOW != 0;
@@ -946,6 +951,11 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
     // shadow rays start on a surface, among the primitives, at every level: the behind-origin test pays
     const int mode = cull ? 2 : 0;
     const bool lean = A.scene.lean != 0;
+    if (variant) {
+        if (work || mode == 0) *variant = mode;
+        else if (A.shadow_mode == 1 || A.shadow_mode == 2) *variant = lean ? LEAN_SH : 2;
+        else *variant = lean ? LEAN_SH : (gen_stays ? GEN_SH : 2);
+    }
     if (work) {
         if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);
         else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);

@@ -123,9 +123,9 @@ struct DeinterleaveArgs {
 #define RT_DECLARE_LAUNCHERS(NS)                                                                                     \
     namespace NS {                                                                                                   \
     hipError_t init_kernels();                                                                                       \
-    hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st); \
+    hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant); \
     hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, \
-                             uint32_t grid, hipStream_t st);                                                         \
+                             uint32_t grid, hipStream_t st, int* variant);                                           \
     hipError_t launch_light(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work,         \
                             uint32_t grid, hipStream_t st);                                                          \
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \

@@ -6,14 +6,31 @@ render a whole frame in test time.  Size-independent properties instead:
   (portable pow), i.e. well inside the 1 LSB / 99.9 % bar;
 - the ray counts add up: one shadow ray per light per lit hit, one node per ray.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
+from conftest import FIXTURE_DIR
+from golden.make_tree_hashes import tree_hash
+from test_host import canonical
+
 pytestmark = pytest.mark.gpu
+
+with open(os.path.join(FIXTURE_DIR, "tree_hashes.json")) as f:
+    TREE_HASHES = json.load(f)["scenes"]
 
 
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
+
+
+def pinned_tree(key, nodes, refs):
+    """Whether the library's partition is, bit for bit, the one the CPU oracle's own builder made of the
+    same scene (tests/golden/tree_hashes.json, written by tests/golden/make_tree_hashes.py)."""
+    want = TREE_HASHES[key]
+    return len(nodes) == want["nodes"] and len(refs) == want["leaf_refs"] and tree_hash(*canonical(nodes, refs)) == want["sha256"]
 
 
 CASES = [
@@ -31,6 +48,8 @@ CASES = [
 def test_full_size_properties(rtamd, oracle, spd, gpu_ctx, gen, kw, w, h, depth, rows):
     text = spd.GENERATORS[gen](width=w, height=h, **kw)
     sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=8)
+    if (gen, kw.get("size")) == ("rings", 6):
+        assert pinned_tree("rings6", *sc.tree())
     cf, cu, cst = sc.render(rtamd.RenderOptions(max_depth=depth), w, h)
     ef, eu, est = sc.render(rtamd.RenderOptions(max_depth=depth, exhaustive_leaves=True), w, h)
     assert np.array_equal(bits(cf), bits(ef)) and np.array_equal(cu, eu)
@@ -88,6 +107,10 @@ def test_mount_8_with_8_lights_at_8k(rtamd, oracle, spd, gpu_ctx):
     del tf, tu, ef, eu
     # rows of the frame from the oracle, on the library's tree after the oracle has checked it
     nodes, refs = sc.tree()
+    # ... which must first be the tree the oracle's own O(n^2) builder makes of this scene (minutes of CPU,
+    # spent once by tests/golden/make_tree_hashes.py): the top of the 131k-triangle tree, whose nodes the
+    # device costs, is then checked by something outside the product as well
+    assert pinned_tree("mount8_lights8", nodes, refs)
     o = oracle.OracleScene(text, build_threads=16, tree=(nodes, refs), verify_max=2048)
     assert o.tree_checked[0] > 10 * o.tree_checked[1] and o.info.max_leaf == sc.tree_info.max_leaf
     rows = (701, 2160, 3517)  # sky and far terrain, the glass spheres, near terrain
@@ -106,6 +129,7 @@ def test_tetra_at_8k(rtamd, oracle, spd, gpu_ctx):
     assert e.value.code == rtamd.RT_ERR_BUILD and "an enclosing call already had" in str(e.value)
     text = spd.tetra(6, w, h)
     sc = rtamd.Scene.from_nff(gpu_ctx, text, build_threads=16)
+    assert pinned_tree("tetra6", *sc.tree())
     cf, cu, cst = sc.render(rtamd.RenderOptions(max_depth=depth), w, h)
     ef, eu, est = sc.render(rtamd.RenderOptions(max_depth=depth, exhaustive_leaves=True), w, h)
     assert np.array_equal(bits(cf), bits(ef)) and np.array_equal(cu, eu)

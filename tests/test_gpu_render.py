@@ -37,6 +37,9 @@ def bits(a):
 FAST_REPORT = []  # (differing fraction, > 1 LSB fraction, max difference) of the scenes fast mode is only reported on
 
 
+FAST_LOOSE_BAR = 3e-2  # fraction of pixels RT_FP_FAST may put off by more than 1 LSB on scenes with chains of mirrors or glass
+
+
 def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, height=0, work=True, fast_bar=1e-3):
     sc = rtamd.Scene.from_nff(gpu_ctx, text, use_phong=phong)
     o = oracle.OracleScene(text, use_phong=phong)
@@ -70,8 +73,10 @@ def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, heig
     # fast mode.  fast_bar = 1e-3 is the north-star tolerance (at most that fraction of pixels off by more
     # than 1 LSB), asserted on scenes without chains of curved mirrors or glass.  On the others fast_bar
     # is None: RT_FP_FAST is documented as outside that tolerance there (any change of rounding
-    # decorrelates a path after a few bounces), so the fraction is reported, not bent into a bar; what
-    # is asserted is only that the picture is the same picture (mean difference under one LSB).
+    # decorrelates a path after a few bounces), so the fraction is reported and held to a loose bar only
+    # (FAST_LOOSE_BAR, several times what these scenes measure: a broken reciprocal slab test or a wrong
+    # margin in the shared traversal would put far more pixels off), and the picture must be the same
+    # picture (mean difference under one LSB).
     _, fu, fst = sc.render(rtamd.RenderOptions(max_depth=depth, fp_mode=rtamd.FP_FAST), width, height, want_f32=False)
     any_diff, big_diff, worst = lsb_report(fu, ou_l)
     if fast_bar is not None:
@@ -80,6 +85,7 @@ def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, heig
         FAST_REPORT.append((any_diff, big_diff, worst))
         print("RT_FP_FAST vs reference arithmetic: %.4f %% of pixels differ, %.4f %% by more than 1 LSB (max %d)"
               % (100 * any_diff, 100 * big_diff, worst))
+        assert big_diff <= FAST_LOOSE_BAR, (any_diff, big_diff, worst)
         assert np.abs(fu.astype(np.int32) - ou_l.astype(np.int32)).mean() < 1.0
     return st, fst
 
@@ -499,6 +505,49 @@ def test_two_frames_in_flight(rtamd, oracle, gpu_ctx):
     assert np.array_equal(snaps[1].cpu().numpy(), sc.render(rtamd.RenderOptions(max_depth=0), 96, 64, want_f32=False)[1])
 
 
+@pytest.mark.parametrize("gen,kw", [("balls", dict(size=2)), ("rings", dict(size=2)), ("mount", dict(size=4, lights=2))])
+def test_orbit_frames_in_flight_equal_one_at_a_time(rtamd, spd, gpu_ctx, gen, kw):
+    """A camera going round the scene, eight frames, as many in flight as there are slots: every frame's
+    grids and pools are sized by ANOTHER view's level sizes (the last finished frame's), which may cost
+    time or a re-run, never a ray: each image equals the one-at-a-time render of its view, bit for bit,
+    and so do the ray counts."""
+    import torch
+    w, h, depth = 320, 200, 6
+    sc = rtamd.Scene.from_nff(gpu_ctx, spd.GENERATORS[gen](width=w, height=h, **kw))
+    v0 = sc.view(w, h)
+    frm, at, up = (np.array(list(x), dtype=np.float64) for x in (v0.from_, v0.at, v0.up))
+    axis = up / np.linalg.norm(up)
+    arm = frm - at
+    views = []
+    for k in range(8):
+        a = 2.0 * np.pi * (k + 1) / 8
+        r = arm * np.cos(a) + np.cross(axis, arm) * np.sin(a) + axis * np.dot(axis, arm) * (1.0 - np.cos(a))
+        views.append(sc.view(w, h, from_=tuple(at + r)))
+    stream = torch.cuda.current_stream().cuda_stream
+    opt = rtamd.RenderOptions(max_depth=depth)
+    one = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    want, want_st = [], []
+    for v in views:
+        want_st.append(sc.render_device(opt, one.data_ptr(), None, stream, view=v))
+        torch.cuda.synchronize()
+        want.append(one.cpu().numpy().copy())
+    sc.render_device(opt, one.data_ptr(), None, stream, view=views[0])  # the hint the first orbit frame starts from
+    outs = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for _ in views]
+    tickets, got_st = [], []
+    for k, v in enumerate(views):
+        if len(tickets) == gpu_ctx.frames_in_flight:
+            got_st.append(sc.render_device_end(tickets.pop(0)))
+        tickets.append(sc.render_device_begin(opt, outs[k].data_ptr(), None, stream, view=v))
+    while tickets:
+        got_st.append(sc.render_device_end(tickets.pop(0)))
+    torch.cuda.synchronize()
+    assert len({st.rays_total for st in want_st}) > 4  # the views do differ
+    for k in range(len(views)):
+        assert np.array_equal(bits(outs[k].cpu().numpy()), bits(want[k])), k
+        for key in RAY_KEYS:
+            assert got_st[k].as_dict()[key] == want_st[k].as_dict()[key], (k, key)
+
+
 def test_one_context_over_several_devices(rtamd, oracle):
     """rt_context_create with more than one device: every device traces its interleaved tiles, peer
     copies bring them to the first device, one de-interleave gives the caller the whole image.  On
@@ -525,10 +574,60 @@ def test_one_context_over_several_devices(rtamd, oracle):
         with pytest.raises(rtamd.RtError) as e:
             sc.render(rtamd.RenderOptions(tile_rank=0, tile_count=2))
         assert e.value.code == rtamd.RT_ERR_UNSUPPORTED
+        # how each rank's tiles reach the root is reported, not swallowed (here: the same device)
+        for r in range(len(devices)):
+            direct, note = ctx.peer_access(r)
+            assert direct == 1 and note, (r, direct, note)
         with pytest.raises(rtamd.RtError):
-            sc.render_device_begin(rtamd.RenderOptions(), None, out.data_ptr(), None, 203, 117)
+            ctx.peer_access(len(devices))
     with pytest.raises(rtamd.RtError):
         rtamd.Context([0, 99])
+
+
+@pytest.mark.parametrize("devices", ([0, 0], [0, 0, 0]))
+def test_frames_in_flight_over_several_devices(rtamd, oracle, devices):
+    """rt_render_device_begin / _end on a context over several devices: three frames of different views and
+    sizes queued before the first is ended (every rank's share of every frame in a slot of its own, with
+    its own tile and gather buffers), then as many as there are slots; every image equals the oracle's, bit
+    for bit, and a copy queued on the caller's stream right behind a frame sees that frame."""
+    import torch
+    text = read_nff("extra-glass")
+    o = oracle.OracleScene(text)
+    ctx = rtamd.Context(devices)
+    sc = rtamd.Scene.from_nff(ctx, text)
+    stream = torch.cuda.current_stream().cuda_stream
+    # (frames like the last finished one -- same size and depth -- are queued without being waited for;
+    # the others are settled inside begin: both kinds, interleaved)
+    views = [(203, 117, 5, (0.0, -6.0, 2.5)), (203, 117, 5, (2.0, -6.0, 2.0)), (203, 117, 5, (-1.5, -5.5, 3.0)), (64, 64, 8, (0.0, -6.0, 2.5)),
+             (203, 117, 5, (0.5, -6.5, 2.2)), (203, 117, 5, (1.0, -6.0, 2.8)), (203, 117, 5, (-2.0, -6.0, 2.0)), (96, 64, 6, (0.0, -6.0, 2.5))]
+    want = []
+    for (w, h, depth, frm) in views:
+        p = oracle.OracleScene(text.replace(b"from 0 -6 2.5", ("from %g %g %g" % frm).encode()))
+        want.append(p.render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, threads=8))
+    for in_flight in (3, ctx.frames_in_flight):
+        outs_u8 = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for (w, h, _, _) in views]
+        outs_f32 = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda") for (w, h, _, _) in views]
+        copies, tickets, stats = [], [], []
+        for k, (w, h, depth, frm) in enumerate(views):
+            if len(tickets) == in_flight:
+                stats.append(sc.render_device_end(tickets.pop(0)))
+            v = sc.view(w, h, from_=frm)
+            tickets.append(sc.render_device_begin(rtamd.RenderOptions(max_depth=depth), outs_f32[k].data_ptr(), outs_u8[k].data_ptr(),
+                                                  stream, w, h, view=v))
+            copies.append(outs_u8[k].clone())
+        if in_flight == ctx.frames_in_flight:  # every slot in flight: one more is refused, and refusing disturbs nothing
+            with pytest.raises(rtamd.RtError):
+                sc.render_device_begin(rtamd.RenderOptions(), None, outs_u8[0].data_ptr(), stream, 64, 64)
+        while tickets:
+            stats.append(sc.render_device_end(tickets.pop(0)))
+        torch.cuda.synchronize()
+        for k, (of, ou, octr, _) in enumerate(want):
+            assert np.array_equal(bits(outs_f32[k].cpu().numpy()), bits(of)), (in_flight, k)
+            assert np.array_equal(outs_u8[k].cpu().numpy(), ou) and np.array_equal(copies[k].cpu().numpy(), ou), (in_flight, k)
+            for key in RAY_KEYS:
+                assert stats[k].as_dict()[key] == octr[key], (in_flight, k, key)
+    with pytest.raises(rtamd.RtError):
+        sc.render_device_end(0)  # nothing in flight under that ticket
 
 
 def test_tile_gather_over_rccl_with_one_rank(rtamd, oracle, gpu_ctx):

@@ -13,7 +13,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import NFF_DIR, REFERENCE_FIXTURES, ROOT, read_nff
+from conftest import FIXTURE_DIR, NFF_DIR, REFERENCE_FIXTURES, ROOT, read_nff
 
 EXTRA = ("extra-glass", "extra-patch", "extra-cones", "extra-onplane")
 
@@ -132,6 +132,23 @@ def test_exact_tree_build_matches_oracle(rtamd, oracle, spd):
         assert (info.n_leaves, info.n_leaf_refs, info.max_depth, info.max_leaf) == (
             oi.leaves, oi.leaf_refs, oi.max_depth, oi.max_leaf)
     assert some_interior
+
+
+def test_big_scene_partitions_equal_the_oracles_own(rtamd, spd):
+    """tests/golden/tree_hashes.json holds SHA-256 of the partitions the CPU oracle's builder made of the
+    largest benchmark scenes (minutes of CPU for the 131k-triangle one, so not rebuilt here; the GPU tests
+    hold the device-costed build of that scene to its hash): the host builder on the two that take seconds."""
+    import json
+    from golden.make_tree_hashes import SCENES, tree_hash
+    with open(os.path.join(FIXTURE_DIR, "tree_hashes.json")) as f:
+        want = json.load(f)["scenes"]
+    assert {"mount8_lights8", "tetra6", "rings6"} <= set(want) and want["mount8_lights8"]["primitives"] == 131076
+    for key, gen, kw in SCENES:
+        if key == "mount8_lights8":
+            continue
+        _, nodes, refs = rtamd.ParsedScene(spd.GENERATORS[gen](**kw)).build_tree(threads=4)
+        assert (len(nodes), len(refs)) == (want[key]["nodes"], want[key]["leaf_refs"]), key
+        assert tree_hash(*canonical(nodes, refs)) == want[key]["sha256"], key
 
 
 def test_tree_build_thread_count_does_not_change_tree(rtamd, spd):
