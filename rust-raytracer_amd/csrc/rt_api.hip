@@ -69,7 +69,7 @@ struct Workspace {
     uint32_t *hit_p = nullptr, *sray_blocked = nullptr;
     uint2* node_sh = nullptr;
     uint4* node_kid = nullptr;
-    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_count[RT_MAX_LEVELS] | overflow | work_next[2 * RT_MAX_LEVELS]
+    // level_count[RT_MAX_LEVELS] | level_base[RT_MAX_LEVELS] | shadow_count[RT_MAX_LEVELS] | overflow | work_next[2 * RT_MAX_LEVELS] | deep_max
     uint32_t* levels = nullptr;
     unsigned long long* counters = nullptr;
     size_t pool_cap = 0;    // ray-tree nodes
@@ -106,6 +106,7 @@ struct FrameSlot {
     int finish_rc = 0;
     rt_stats stats{};
     bool one_stream = false;  // this frame's shadow launches go to the main stream too
+    bool fused = false;       // this frame's levels below the camera rays ran as one launch
     const rt_scene* scene = nullptr;
     rt_view view{};
     rt_options opt{};
@@ -153,6 +154,7 @@ struct rt_context {
     DevBuf<float> out_f32;
     DevBuf<uint8_t> out_u8;
     bool kernels_ready = false;
+    bool fuse_deep = true;               // all levels below the camera rays in one launch where the kernels allow (RTAMD_FUSE_DEEP=0: never)
     // Sizes of the last finished frame's levels: how many blocks the next frame of the same scene and
     // size launches per level.  Only a hint -- every kernel strides over its level whatever the grid.
     uint64_t hint_scene = 0;  // rt_scene::serial (a number, not an address: a scene created where a destroyed one lay is another scene)
@@ -183,7 +185,7 @@ struct rt_scene {
 namespace {
 
 constexpr uint32_t LV_SHADOW_COUNT = 2 * RT_MAX_LEVELS, LV_OVERFLOW = 3 * RT_MAX_LEVELS, LV_WORK_NEXT = 3 * RT_MAX_LEVELS + 1,
-                   LV_WORDS = 5 * RT_MAX_LEVELS + 1;
+                   LV_DEEP_MAX = 5 * RT_MAX_LEVELS + 1, LV_WORDS = 5 * RT_MAX_LEVELS + 2;
 constexpr uint32_t N_COUNTERS = 40;  // see FrameArgs::counters
 constexpr uint32_t SHADOW_GROUP_FROM = 4;  // levels from here on are too small to fill the GPU: one shadow launch for all
 
@@ -346,6 +348,7 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         f.ws.levels = f.levels.p;
         f.ws.counters = f.counters.p;
     }
+    if (const char* s = getenv("RTAMD_FUSE_DEEP")) ctx->fuse_deep = strtoul(s, nullptr, 10) != 0;
     if (const char* s = getenv("RTAMD_WORKSPACE_MAX_MB")) ctx->workspace_limit = (uint64_t)strtoull(s, nullptr, 10) << 20;
     // The entry point that allocates nothing works in the static array: this device's copy of it
     // is looked up here, with the device current, and its slot's streams, events and pinned
@@ -792,6 +795,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.shadow_count = ws.levels + LV_SHADOW_COUNT;
     A.overflow = ws.levels + LV_OVERFLOW;
     A.work_next = ws.levels + LV_WORK_NEXT;
+    A.deep_max = ws.levels + LV_DEEP_MAX;
     A.counters = ws.counters;
 
     // Levels that cannot hold a ray are not launched.  A ray of level k carries a contribution of
@@ -862,7 +866,38 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         return RT_OK;
     };
     bool lit_level0 = false;  // level 0's lighting is queued already
-    for (uint32_t level = 0; level <= last_level; ++level) {
+    // All levels below the camera rays in one launch, where the kernels for that exist (lean scenes): the
+    // frame is then level 0, that launch, and the shadow rays of both.
+    const bool fused = !work && cull && ctx->fuse_deep && (fast ? rt_fast::can_fuse(A, last_level) : rt_exact::can_fuse(A, last_level));
+    A.fused = fused ? 1u : 0u;
+    f.fused = fused;
+    if (fused) {
+        RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, 0, work, cull, grid0, st, nullptr) : rt_exact::launch_intersect(A, 0, work, cull, grid0, st, nullptr));
+        if (serial) RT_HIP(ctx, hipEventRecord(f.ev_t[0], st));
+        if (n_lights) {
+            RT_HIP(ctx, hipEventRecord(f.ev_level[0], st));
+            if (!one_stream) {
+                rc = shadow_rays(0, 0);
+                if (rc != RT_OK) return rc;
+                RT_HIP(ctx, fast ? rt_fast::launch_light(A, 0, 0, work, grid0, st2) : rt_exact::launch_light(A, 0, 0, work, grid0, st2));
+                lit_level0 = true;
+            }
+        }
+        // (blocks stay and take rays from the launch's counter: as many as the level-1 rays can use)
+        const uint32_t gd = blocks_for(ctx->hint_rays[1], gridn);
+        RT_HIP(ctx, fast ? rt_fast::launch_deep(A, gd, st, &f.variant_deep) : rt_exact::launch_deep(A, gd, st, &f.variant_deep));
+        if (serial) {
+            RT_HIP(ctx, hipEventRecord(f.ev_t[1], st));
+            f.timed_levels = 2;
+        }
+        if (n_lights) {
+            RT_HIP(ctx, hipEventRecord(f.ev_level[last_level], st));
+            rc = shadow_rays(one_stream ? 0 : 1, last_level);
+            if (rc != RT_OK) return rc;
+            if (serial) RT_HIP(ctx, hipEventRecord(f.ev_t[f.timed_levels], st));
+        }
+    }
+    for (uint32_t level = 0; level <= last_level && !fused; ++level) {
         const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
         int* variant = level > 0 ? &f.variant_deep : nullptr;
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st, variant) : rt_exact::launch_intersect(A, level, work, cull, g, st, variant));
@@ -911,7 +946,8 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     }
     RT_HIP(ctx, hipEventRecord(f.ev[1], st));
     for (uint32_t level = last_level + 1; level-- > 0;) {
-        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
+        // (fused: hint_rays[2] is the size of the range all levels from 2 on share, which each of their launches goes over)
+        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[fused && level > 2 ? 2 : level], gridn);
         if (level == 0) RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_caller, 0));  // the caller's buffers are written from here on
         RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));
     }
@@ -941,6 +977,9 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
         uint64_t need = p.n_slots, sneed = 0;
         for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed += lv[LV_SHADOW_COUNT + l];
         for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
+        if (lv[LV_OVERFLOW] >= 0x100u)  // (k_deep: a wave waited longer than any walk can last and gave up)
+            return fail(ctx, RT_ERR_DEVICE, "internal: the kernel of the deeper levels gave up a wait (" + std::to_string(lv[LV_OVERFLOW] - 0x100u) +
+                                                "); nothing was written to the outputs");
         if (lv[LV_OVERFLOW] != 0) {  // a pool overflowed: grow and run the frame again
             if (f.fixed)
                 return fail(ctx, RT_ERR_CAPACITY,
@@ -990,6 +1029,7 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
             stats.ray_nodes += lv[l];
             if (lv[l]) stats.levels = l + 1;
         }
+        if (f.fused && lv[1] != 0) stats.levels = std::max<uint32_t>(2, lv[LV_DEEP_MAX] + 1);  // (levels from 2 on share lv[2])
         float ms01 = 0, ms12 = 0, ms02 = 0;
         RT_HIP(ctx, hipEventElapsedTime(&ms01, f.ev[0], f.ev[1]));
         RT_HIP(ctx, hipEventElapsedTime(&ms12, f.ev[1], f.ev[2]));

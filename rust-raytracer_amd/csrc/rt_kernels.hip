@@ -99,6 +99,15 @@ RT_DEV uint32_t level_size(const FrameArgs& A, uint32_t level, uint32_t base) {
     return wanted < room ? wanted : room;
 }
 
+// End of the pool's nodes of levels 0 .. last_level.
+RT_DEV uint32_t nodes_end(const FrameArgs& A, uint32_t last_level) {
+    if (A.fused != 0u && last_level >= 2u) {  // (all levels from 2 on share one range)
+        const uint32_t base2 = A.level_base[2];
+        return base2 + level_size(A, 2u, base2);
+    }
+    return A.level_base[last_level + 1];
+}
+
 struct Ray {
     F3 src, dir;
     float near, contribution;
@@ -152,6 +161,65 @@ RT_DEV uint32_t shadow_first(const FrameArgs& A, uint32_t level) {
     uint32_t s = 0;
     for (uint32_t j = 0; j < level; ++j) s += A.shadow_count[j];
     return s;
+}
+
+// The rays a hit spawns (src/scene.rs:127-193), and the weights its node keeps for them.
+struct Spawn {
+    bool want_refl = false, want_refr = false;
+    F3 refl_ray, refr_ray;
+    float reflectance = 0.0f, transmittance = 0.0f, refl_contrib = 0.0f, refr_contrib = 0.0f;
+};
+RT_DEV Spawn spawn_of(const FrameArgs& A, const Ray& ray, const Hit& hit, bool is_hit, uint32_t level) {
+    const DevScene& S = A.scene;
+    Spawn sp;
+    sp.refl_ray = f3(0, 0, 0);
+    sp.refr_ray = f3(0, 0, 0);
+    if (is_hit && level < A.max_depth) {
+        const Surface surf = load_surface(S, S.prim_surface[hit.prim]);
+        const bool back_face = dot(hit.n, ray.dir) > 0.0f;  // :96
+        if (!back_face) {  // :127-144
+            sp.refl_contrib = ray.contribution * surf.reflectance;
+            if (sp.refl_contrib > A.min_contribution) {
+                sp.want_refl = true;
+                sp.refl_ray = reflect(ray.dir, hit.n);
+                sp.reflectance = surf.reflectance;
+            }
+        }
+        // :147-193
+        if (back_face) sp.transmittance = surf.transmittance > A.min_contribution ? 1.0f : 0.0f;
+        else sp.transmittance = surf.transmittance;
+        sp.refr_contrib = ray.contribution * sp.transmittance;
+        if (sp.refr_contrib > A.min_contribution) {
+            sp.want_refr = true;
+            sp.refr_ray = back_face ? refract(ray.dir, neg(hit.n), 1.0f / surf.ior) : refract(ray.dir, hit.n, surf.ior);
+        }
+    }
+    return sp;
+}
+
+// One shadow ray per light for a front-face hit at `pos` (src/scene.rs:103-112), into slot `first` of
+// every light's queue.
+template <class Ctr>
+RT_DEV void put_shadow_rays(const FrameArgs& A, F3 pos, uint32_t hit_prim, uint32_t first, Ctr& ctr) {
+    const DevScene& S = A.scene;
+    for (uint32_t l = 0; l < S.n_lights; ++l) {
+        ctr.light_evals(1);
+        const float4 lp = S.lights[l * 2];
+        const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
+        const float ldist = magnitude(to_light);
+        const F3 ldir = divs(to_light, ldist);
+        const uint64_t s = (uint64_t)l * A.shadow_cap + first;
+        A.sray_o[s] = make_float4(pos.x, pos.y, pos.z, ldist);
+        A.sray_d[s] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(hit_prim));
+    }
+}
+
+// A spawned ray in its pool slot.  Until the ray is traced, the slot's hit_p word holds the ray's level
+// (the kernel that traces every deeper level in one launch reads it from there).
+RT_DEV void put_ray(const FrameArgs& A, uint32_t idx, F3 pos, F3 dir, float contribution, uint32_t ignore, uint32_t level) {
+    A.ray_o[idx] = make_float4(pos.x, pos.y, pos.z, contribution);
+    A.ray_d[idx] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(ignore));
+    A.hit_p[idx] = level;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -224,29 +292,9 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
 
         // ---- the rays this hit spawns (src/scene.rs:127-193); the node keeps {background or 0,
         // reflectance weight} and the child links, k_light adds the direct light later
-        bool want_refl = false, want_refr = false;
-        F3 refl_ray = f3(0, 0, 0), refr_ray = f3(0, 0, 0);
-        float reflectance = 0.0f, transmittance = 0.0f, refl_contrib = 0.0f, refr_contrib = 0.0f;
-        if (is_hit && level < A.max_depth) {
-            const Surface surf = load_surface(S, S.prim_surface[hit.prim]);
-            const bool back_face = dot(hit.n, ray.dir) > 0.0f;  // :96
-            if (!back_face) {  // :127-144
-                refl_contrib = ray.contribution * surf.reflectance;
-                if (refl_contrib > A.min_contribution) {
-                    want_refl = true;
-                    refl_ray = reflect(ray.dir, hit.n);
-                    reflectance = surf.reflectance;
-                }
-            }
-            // :147-193
-            if (back_face) transmittance = surf.transmittance > A.min_contribution ? 1.0f : 0.0f;
-            else transmittance = surf.transmittance;
-            refr_contrib = ray.contribution * transmittance;
-            if (refr_contrib > A.min_contribution) {
-                want_refr = true;
-                refr_ray = back_face ? refract(ray.dir, neg(hit.n), 1.0f / surf.ior) : refract(ray.dir, hit.n, surf.ior);
-            }
-        }
+        const Spawn sp = spawn_of(A, ray, hit, is_hit, level);
+        bool want_refl = sp.want_refl, want_refr = sp.want_refr;
+        const float reflectance = sp.reflectance, transmittance = sp.transmittance;
 
         // ---- room in the shadow queue (one slot per front-face hit) and in the next level (reflection
         // slots first, then refraction).  An add on one counter takes the memory system 11 ns whoever
@@ -311,18 +359,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
             const bool fits = slot0 + c_lit <= A.shadow_cap;
             if (!fits) *A.overflow = 1u;
             A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
-            if (fits) {
-                for (uint32_t l = 0; l < n_lights; ++l) {  // src/scene.rs:103-112
-                    ctr.light_evals(1);
-                    const float4 lp = S.lights[l * 2];
-                    const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
-                    const float ldist = magnitude(to_light);
-                    const F3 ldir = divs(to_light, ldist);
-                    const uint64_t s = (uint64_t)l * A.shadow_cap + first;
-                    A.sray_o[s] = make_float4(pos.x, pos.y, pos.z, ldist);
-                    A.sray_d[s] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(hit.prim));
-                }
-            }
+            if (fits) put_shadow_rays(A, pos, hit.prim, first, ctr);
         }
         if (i < count && !lit) A.node_sh[node] = make_uint2(NONE, 0u);  // also the padding slots of edge tiles
 
@@ -335,18 +372,16 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
         if (want_refr && refr_idx >= A.pool_cap) { refr_idx = NONE; want_refr = false; *A.overflow = 1u; }
         if (want_refl) {
             if (by_wave) ++n_refl;
-            A.ray_o[refl_idx] = make_float4(pos.x, pos.y, pos.z, refl_contrib);
-            A.ray_d[refl_idx] = make_float4(refl_ray.x, refl_ray.y, refl_ray.z, __uint_as_float(hit.prim));
+            put_ray(A, refl_idx, pos, sp.refl_ray, sp.refl_contrib, hit.prim, level + 1u);
         }
         if (want_refr) {
             if (by_wave) ++n_refr;
-            A.ray_o[refr_idx] = make_float4(pos.x, pos.y, pos.z, refr_contrib);
-            A.ray_d[refr_idx] = make_float4(refr_ray.x, refr_ray.y, refr_ray.z, __uint_as_float(NO_PRIM));
+            put_ray(A, refr_idx, pos, sp.refr_ray, sp.refr_contrib, NO_PRIM, level + 1u);
         }
         if (active) {
             const F3 total = is_hit ? f3(0.0f, 0.0f, 0.0f) : f3(S.bg[0], S.bg[1], S.bg[2]);  // :199, never clamped
             A.node_col[node] = make_float4(total.x, total.y, total.z, reflectance);
-            A.node_kid[node] = make_uint4(refl_idx, refr_idx, __float_as_uint(transmittance), is_hit ? 1u : 0u);
+            A.node_kid[node] = make_uint4(refl_idx, refr_idx, __float_as_uint(transmittance), (is_hit ? 1u : 0u) | (level << 1));
         }
     }
     if (by_wave) {
@@ -360,6 +395,258 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
         if (block_refr) atomicAdd(&A.counters[3], (unsigned long long)block_refr);
     }
     flush_work(A, ctr);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_deep: every level below the camera rays in ONE launch.  Per level a launch cannot end before its
+// slowest wave's walk has, and the next level waits for it: eight dwindling levels are eight such
+// waits in a row.  Here a block that traced rays goes on with the rays THEY spawned: no launch, and no
+// block, ever waits for another (so two frames' kernels can share the device without a deadlock), and
+// a ray's descendants follow it as fast as one wave after the other can walk.
+//   Level 1 is a range of the pool (the camera rays' children, complete when this kernel starts); waves
+// take runs of it from the launch's counter.  Deeper rays go to the one range behind it, in the order of
+// their reservations (one add per wave and batch on level_count[2]; lit hits likewise on shadow_count[1]),
+// their level with them (put_ray).  A wave whose batch spawned (nearly) a full batch goes on with those
+// rays itself; smaller offspring goes to the block's stack in LDS (node indices; a lock taken by one lane),
+// from which waves take 64 at a time -- newest first, so that it stays shallow -- and which they prefer to
+// the launch's level-1 rays once it holds 64.  Offspring that does not fit the stack stays with its wave as
+// a range (each wave has room for two per level), so nothing ever waits for room.  When the level-1 rays
+// are used up, waves take what the stack holds, however little; a block is done when its stack is empty
+// and none of its waves holds rays.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t DEEP_STACK = 2048u;        // node indices a block's stack holds
+constexpr uint32_t DEEP_MAX_LEVEL = 16u;      // deepest max_depth this kernel serves (per-wave ranges below)
+constexpr uint32_t DEEP_RANGES = 2u * DEEP_MAX_LEVEL + 8u;
+constexpr uint32_t DEEP_KEEP = 48u;           // offspring of at least this many rays stays with its wave
+struct DeepCtl {
+    uint32_t lock, top, active, level1_done;
+};
+
+// Every wait of this kernel is bounded: a wave that waits longer than any walk can last gives up, flags the
+// frame (overflow word = DEEP_STUCK + where) and leaves, so that a mistake here ends a frame, not the GPU.
+constexpr uint32_t DEEP_STUCK = 0x100u;
+RT_DEV bool deep_lock(DeepCtl* c) {
+    uint32_t ok = 1u;
+    if (lane_id() == 0) {
+        uint32_t spins = 0;
+        while (atomicCAS(&c->lock, 0u, 1u) != 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 20)) { ok = 0u; break; }
+        }
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok != 0u;
+}
+// A word of the block's control block, read or written for what it holds now (never kept in a register).
+RT_DEV uint32_t lds_peek(uint32_t* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+RT_DEV void lds_poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RT_DEV void deep_unlock(DeepCtl* c) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane_id() == 0) atomicExch(&c->lock, 0u);
+}
+
+template <int CULL, class Ctr>
+__global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_deep(FrameArgs A) {
+    extern __shared__ uint2 lds_stack[];
+    __shared__ DeepCtl ctl;
+    __shared__ uint32_t q_idx[DEEP_STACK];
+    __shared__ uint2 q_ranges[RT_MAX_BLOCK_WAVES][DEEP_RANGES];  // per wave: {first node, count} of rays it keeps for itself
+
+    const DevScene& S = A.scene;
+    const uint32_t base1 = A.level_base[1];
+    const uint32_t count1 = level_size(A, 1u, base1);
+    const uint32_t base2 = base1 + count1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.level_base[2] = base2;
+    if (block_late(&A.work_next[1], count1, &ctl.lock)) return;  // a block that comes when the level-1 rays are used up
+    if (threadIdx.x == 0) {
+        ctl.lock = 0u; ctl.top = 0u; ctl.active = 0u; ctl.level1_done = 0u;
+    }
+    stage_scene<CULL>(S, lds_stack);  // (ends with a barrier)
+    const uint32_t n_lights = S.n_lights;
+    const uint32_t sh_base = A.shadow_count[0];  // level 0 is complete: its lit hits come first in the queues
+    const uint32_t lane = lane_id();
+    uint2* const ranges = q_ranges[threadIdx.x >> 6];
+    // (runs of level-1 rays per visit to the launch's counter: more on big levels, where one address would not
+    // take an add per 64 rays fast enough)
+    const uint32_t take1 = count1 >= (1u << 22) ? LEAN_TAKE : 64u;
+    Ctr ctr;
+    uint32_t n_ranges = 0;   // (the same in every lane)
+    bool counted = false;    // this wave is one of ctl.active: it holds rays, or is fetching some
+    uint32_t n_refl = 0, n_refr = 0, deepest = 0, idle_polls = 0;
+    for (;;) {
+        // ---- the next batch: up to 64 nodes
+        uint32_t node = NONE;
+        if (n_ranges != 0u) {  // rays this wave kept
+            const uint2 r = ranges[n_ranges - 1u];
+            const uint32_t take = r.y < 64u ? r.y : 64u;
+            if (lane < take) node = r.x + lane;
+            if (r.y > take) {
+                if (lane == 0) ranges[n_ranges - 1u] = make_uint2(r.x + take, r.y - take);
+            } else {
+                --n_ranges;
+            }
+        } else {
+            // What there is to take, read WITHOUT the lock (seven idle waves that took it for every look starved
+            // the one wave that had rays to push: the lock is for the stack's entries alone).  LDS operations of a
+            // wave run in order and ctl.active only changes by atomic adds, so a wave that sees another's
+            // un-count also sees what that wave pushed before it.
+            const uint32_t l1_done = lds_peek(&ctl.level1_done);
+            const uint32_t seen = lds_peek(&ctl.top);
+            if (seen >= 64u || (seen != 0u && l1_done != 0u)) {  // from the block's stack
+                if (!counted) {
+                    if (lane == 0) atomicAdd(&ctl.active, 1u);
+                    counted = true;
+                }
+                if (!deep_lock(&ctl)) { atomicMax(A.overflow, DEEP_STUCK + 1u); break; }
+                const uint32_t top = ctl.top;
+                uint32_t take = top < 64u ? top : 64u;
+                if (top < 64u && l1_done == 0u) take = 0u;  // (another wave was faster)
+                if (lane < take) node = q_idx[top - take + lane];
+                if (lane == 0) ctl.top = top - take;
+                deep_unlock(&ctl);
+                if (take == 0u) continue;
+            } else if (l1_done == 0u) {  // a run of level-1 rays
+                if (!counted) {
+                    if (lane == 0) atomicAdd(&ctl.active, 1u);
+                    counted = true;
+                }
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(&A.work_next[1], take1);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c < count1) {
+                    if (lane == 0) ranges[0] = make_uint2(base1 + c, take1 < count1 - c ? take1 : count1 - c);
+                    n_ranges = 1u;
+                } else if (lane == 0) {
+                    lds_poke(&ctl.level1_done, 1u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (ranges[0] is read by all lanes next)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                continue;
+            } else {  // nothing to take: done if no wave of the block holds rays that could spawn more
+                if (counted) {
+                    if (lane == 0) atomicSub(&ctl.active, 1u);
+                    counted = false;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                }
+                // (in this order: a wave un-counts itself after its last push, so once nobody is counted the
+                // stack holds all there ever will be, bar what a wave that has taken rays since brings on
+                // itself -- and that wave looks here again before it leaves)
+                const uint32_t others = lds_peek(&ctl.active);
+                const uint32_t left = lds_peek(&ctl.top);
+                if (others == 0u && left == 0u) break;
+                if (++idle_polls > (1u << 18)) { atomicMax(A.overflow, DEEP_STUCK + 3u); break; }
+                __builtin_amdgcn_s_sleep(32);
+                continue;
+            }
+        }
+
+        // ---- trace it (as k_intersect does a level's rays; the level differs from lane to lane)
+        const bool active = node != NONE;
+        Ray ray;
+        ray.src = f3(0, 0, 0); ray.dir = f3(1, 0, 0); ray.near = 0.0f; ray.contribution = 0.0f; ray.ignore = NO_PRIM;
+        uint32_t level = 1u;
+        if (active) {
+            fetch_ray<false>(A, 0u, node, ray);
+            level = A.hit_p[node];
+        }
+        bool lit = false, is_hit = false;
+        Hit hit;
+        hit.dist = 0.0f; hit.prim = NO_PRIM; hit.n = f3(0, 0, 0);
+        if (active) {
+            is_hit = kd_traverse_closest<CULL>(S, ray.src, ray.dir, ray.near, ray.ignore, hit, lds_stack, ctr);
+            if (!is_hit) hit.prim = NO_PRIM;
+            A.hit_a[node] = make_float4(hit.n.x, hit.n.y, hit.n.z, hit.dist);
+            A.hit_p[node] = hit.prim;
+            if (is_hit) lit = !(dot(hit.n, ray.dir) > 0.0f) && n_lights > 0;  // src/scene.rs:96, :102
+            deepest = level > deepest ? level : deepest;
+        }
+        const F3 pos = add(ray.src, mul(ray.dir, hit.dist));  // src/scene.rs:95
+        const Spawn sp = spawn_of(A, ray, hit, is_hit, level);
+        bool want_refl = sp.want_refl, want_refr = sp.want_refr;
+
+        const uint64_t m_lit = __ballot(lit);
+        const uint64_t m_refl = __ballot(want_refl);
+        const uint64_t m_refr = __ballot(want_refr);
+        const uint32_t c_lit = (uint32_t)__popcll(m_lit);
+        const uint32_t c_refl = (uint32_t)__popcll(m_refl), c_refr = (uint32_t)__popcll(m_refr);
+        uint32_t lit0 = 0, spawn0 = 0;
+        if (lane == 0) {
+            if (c_lit) lit0 = atomicAdd(&A.shadow_count[1], c_lit);
+            if (c_refl + c_refr) spawn0 = atomicAdd(&A.level_count[2], c_refl + c_refr);
+        }
+        lit0 = __builtin_amdgcn_readfirstlane(lit0);
+        spawn0 = __builtin_amdgcn_readfirstlane(spawn0);
+        if (lit) {
+            const uint32_t slot0 = sh_base + lit0;
+            const uint32_t first = slot0 + prefix_count(m_lit);
+            const bool fits = slot0 + c_lit <= A.shadow_cap;
+            if (!fits) atomicMax(A.overflow, 1u);
+            A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
+            if (fits) put_shadow_rays(A, pos, hit.prim, first, ctr);
+        }
+        if (active && !lit) A.node_sh[node] = make_uint2(NONE, 0u);
+        uint32_t refl_idx = NONE, refr_idx = NONE;
+        if (want_refl) refl_idx = base2 + spawn0 + prefix_count(m_refl);
+        if (want_refr) refr_idx = base2 + spawn0 + c_refl + prefix_count(m_refr);
+        if (want_refl && refl_idx >= A.pool_cap) { refl_idx = NONE; want_refl = false; atomicMax(A.overflow, 1u); }
+        if (want_refr && refr_idx >= A.pool_cap) { refr_idx = NONE; want_refr = false; atomicMax(A.overflow, 1u); }
+        if (want_refl) {
+            ++n_refl;
+            put_ray(A, refl_idx, pos, sp.refl_ray, sp.refl_contrib, hit.prim, level + 1u);
+        }
+        if (want_refr) {
+            ++n_refr;
+            put_ray(A, refr_idx, pos, sp.refr_ray, sp.refr_contrib, NO_PRIM, level + 1u);
+        }
+        if (active) {
+            const F3 total = is_hit ? f3(0.0f, 0.0f, 0.0f) : f3(S.bg[0], S.bg[1], S.bg[2]);  // :199, never clamped
+            A.node_col[node] = make_float4(total.x, total.y, total.z, sp.reflectance);
+            A.node_kid[node] = make_uint4(refl_idx, refr_idx, __float_as_uint(sp.transmittance), (is_hit ? 1u : 0u) | (level << 1));
+        }
+
+        // ---- the offspring: slots [first_kid, first_kid + n_kids) of the pool (what did not fit it is dropped)
+        const uint32_t first_kid = base2 + spawn0;
+        uint32_t n_kids = c_refl + c_refr;
+        if (first_kid >= A.pool_cap) n_kids = 0u;
+        else if (n_kids > A.pool_cap - first_kid) n_kids = A.pool_cap - first_kid;
+        if (n_kids != 0u) {
+            // (the rays just written are read back by this wave or by another of the block)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            bool kept = n_kids >= DEEP_KEEP;
+            if (!kept) {
+                if (!deep_lock(&ctl)) { atomicMax(A.overflow, DEEP_STUCK + 4u); break; }
+                const uint32_t top = ctl.top;
+                if (top + n_kids <= DEEP_STACK) {
+                    if (lane < n_kids) q_idx[top + lane] = first_kid + lane;
+                    if (lane + 64u < n_kids) q_idx[top + lane + 64u] = first_kid + lane + 64u;
+                    if (lane == 0) ctl.top = top + n_kids;
+                } else {
+                    kept = true;
+                }
+                deep_unlock(&ctl);
+            }
+            if (kept) {  // (never more than two ranges per level: a batch leaves one, of at most 128 rays, and the next batch comes off it)
+                if (lane == 0) ranges[n_ranges] = make_uint2(first_kid, n_kids);
+                ++n_ranges;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+    }
+    const uint32_t s_refl = wave_sum(n_refl), s_refr = wave_sum(n_refr);
+    uint32_t d = deepest;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(d, off, 64);
+        d = o > d ? o : d;
+    }
+    if (lane == 0) {
+        if (s_refl) atomicAdd(&A.counters[2], (unsigned long long)s_refl);
+        if (s_refr) atomicAdd(&A.counters[3], (unsigned long long)s_refr);
+        if (d) atomicMax(A.deep_max, d);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -486,7 +773,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t first_
     const DevScene& S = A.scene;
     if (*A.overflow != 0u) return;  // (the frame will be run again)
     const uint32_t first = first_level == 0 ? 0u : A.level_base[first_level];
-    const uint32_t end = A.level_base[last_level + 1];  // both already clamped to the pool
+    const uint32_t end = nodes_end(A, last_level);  // both already clamped to the pool
     Ctr ctr;
     for (uint32_t node = first + blockIdx.x * RT_BLOCK + threadIdx.x; node < end; node += gridDim.x * RT_BLOCK) {
         const uint2 sh = A.node_sh[node];
@@ -538,13 +825,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(FrameArgs A, uint32_t leve
     // An attempt whose pools overflowed dropped rays: its image would be wrong, so it writes none
     // (the caller's buffers keep what they held until the re-run with larger pools).
     if (*A.overflow != 0u) return;
-    const uint32_t base = LEVEL0 ? 0u : A.level_base[level];
-    const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, level, base);
+    // (one launch traced all levels from 1 on: those from 2 on share one range of the pool, and a launch
+    // for one of them goes over that range and takes the nodes of its level)
+    const bool shared_range = !LEVEL0 && A.fused != 0u && level >= 2u;
+    const uint32_t base = LEVEL0 ? 0u : A.level_base[shared_range ? 2u : level];
+    const uint32_t count = LEVEL0 ? A.n_slots : level_size(A, shared_range ? 2u : level, base);
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
         uint32_t px = 0, py = 0;
         if (LEVEL0 && !slot_to_pixel(A, i, px, py)) continue;
         const uint32_t node = base + i;
         const uint4 kid = A.node_kid[node];
+        if (shared_range && (kid.w >> 1) != level) continue;
         float4 col = A.node_col[node];
         if (kid.x != NONE || kid.y != NONE) {
             if (kid.x != NONE) {  // total += reflected * reflectance, src/scene.rs:141-142
@@ -815,6 +1106,7 @@ static const bool g_lean_stays[5] = {RT_STAY_LEVEL0 != 0, RT_STAY_DEEP != 0, RT_
 // Threads per staying block of each lean kernel: RT_LEAN_BLOCKS_PER_CU blocks fill the waves per SIMD the
 // kernel's register use allows (init_kernels).  [0] k_intersect level 0, [1] deeper levels, [2..4] k_shadow by mode.
 static uint32_t g_lean_block[5] = {512, 512, 512, 512, 512};
+static uint32_t g_deep_block = 512;  // the same for k_deep
 // The same for the staying blocks of scenes that are not lean, one block per CU: [0] k_intersect level 0,
 // [1] deeper levels, [2] k_shadow (mode 0); [0] unused.
 static uint32_t g_gen_block[3] = {1024, 1024, 1024};
@@ -859,6 +1151,7 @@ hipError_t init_kernels() {
                          (const void*)k_shadow<2, NoCounters, 1>, (const void*)k_shadow<LEAN_SH, NoCounters, 1>,
                          (const void*)k_shadow<2, NoCounters, 2>, (const void*)k_shadow<LEAN_SH, NoCounters, 2>,
                          (const void*)k_intersect<false, GEN_ID, NoCounters>, (const void*)k_shadow<GEN_SH, NoCounters>,
+                         (const void*)k_deep<LEAN_ID, NoCounters>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
     for (const void* f : fns) {
         hipFuncAttributes fa;
@@ -882,6 +1175,17 @@ hipError_t init_kernels() {
         uint32_t threads = waves * 4u * 64u / RT_LEAN_BLOCKS_PER_CU;
         if (threads > RT_LEAN_BLOCK) threads = RT_LEAN_BLOCK;
         g_lean_block[k] = threads < 64u ? 64u : threads;
+    }
+    {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, (const void*)k_deep<LEAN_ID, NoCounters>);
+        if (e != hipSuccess) return e;
+        const uint32_t regs = ((uint32_t)(fa.numRegs > 0 ? fa.numRegs : 128) + 7u) & ~7u;
+        uint32_t waves = 512u / regs;
+        waves = waves < 1u ? 1u : (waves > 8u ? 8u : waves);
+        uint32_t threads = waves * 4u * 64u / RT_LEAN_BLOCKS_PER_CU;
+        if (threads > RT_LEAN_BLOCK) threads = RT_LEAN_BLOCK;
+        g_deep_block = threads < 64u ? 64u : threads;
     }
     const void* gen_fns[3] = {nullptr, (const void*)k_intersect<false, GEN_ID, NoCounters>, (const void*)k_shadow<GEN_SH, NoCounters>};
     for (int k = 1; k < 3; ++k) {
@@ -924,6 +1228,24 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
         else if (cull) hipLaunchKernelGGL((k_intersect<false, 2, NoCounters>), g, b, lds, st, A, level);
         else hipLaunchKernelGGL((k_intersect<false, 0, NoCounters>), g, b, lds, st, A, level);
     }
+    return hipGetLastError();
+}
+
+// Whether k_deep serves this frame: the production kernels (no counters, culled walk) of lean scenes, to
+// the depth its per-wave ranges allow.
+#ifndef RT_FUSE_DEEP
+#define RT_FUSE_DEEP 1
+#endif
+bool can_fuse(const FrameArgs& A, uint32_t last_level) {
+    return RT_FUSE_DEEP != 0 && A.scene.lean != 0 && g_lean_stays[1] && last_level >= 2u && A.max_depth <= DEEP_MAX_LEVEL;
+}
+
+hipError_t launch_deep(const FrameArgs& A, uint32_t grid, hipStream_t st, int* variant) {
+    const uint32_t tb = g_deep_block;
+    const dim3 g(blocks_of(grid, tb, true, RT_LEAN_BLOCKS_PER_CU)), b(tb);
+    const size_t lds = stack_bytes(A.scene, true, tb, true);
+    if (variant) *variant = LEAN_ID + 32;  // (+ 32: all deeper levels in one launch)
+    hipLaunchKernelGGL((k_deep<LEAN_ID, NoCounters>), g, b, lds, st, A);
     return hipGetLastError();
 }
 

@@ -96,6 +96,12 @@ struct FrameArgs {
     uint32_t pool_cap;
     uint32_t* level_count;  // [RT_MAX_LEVELS]
     uint32_t* level_base;   // [RT_MAX_LEVELS]
+    // fused != 0: every level below the camera rays' children is traced by ONE launch (k_deep).  Level 1 is a
+    // range of the pool as ever; all deeper nodes share the range behind it, in no order of levels ("level 2"
+    // of level_count / level_base stands for all of them, and shadow_count[1] for all lit hits below level 0);
+    // a node's level is kept in node_kid.w >> 1.
+    uint32_t fused;
+    uint32_t* deep_max;     // fused: the deepest level that held a ray
     // shadow-ray queue of the frame
     float4* sray_o;         // origin.xyz, distance to the light
     float4* sray_d;         // direction.xyz, bits(ignored primitive)
@@ -126,6 +132,8 @@ struct DeinterleaveArgs {
     hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant); \
     hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, \
                              uint32_t grid, hipStream_t st, int* variant);                                           \
+    hipError_t launch_deep(const rtamd::FrameArgs& A, uint32_t grid, hipStream_t st, int* variant);                  \
+    bool can_fuse(const rtamd::FrameArgs& A, uint32_t last_level);                                                   \
     hipError_t launch_light(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work,         \
                             uint32_t grid, hipStream_t st);                                                          \
     hipError_t launch_resolve(const rtamd::FrameArgs& A, uint32_t level, uint32_t grid, hipStream_t st);             \

@@ -15,7 +15,7 @@ for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', s, re.S):
                         re.search(r'private_segment_fixed_size (\d+)', m.group(2)).group(1))
 for m in re.finditer(r'^(_ZN8rt_exact\S+):[^\n]*\n(.*?)\.Lfunc_end', s, re.S | re.M):
     name, body = m.group(1), m.group(2)
-    if 'NoCounters' not in name or not ('k_shadow' in name or 'k_intersect' in name):
+    if 'NoCounters' not in name or not ('k_shadow' in name or 'k_intersect' in name or 'k_deep' in name):
         continue
     ins = [l.split()[0] for l in body.split('\n') if l.startswith('\t') and not l.startswith('\t.') and not l.startswith('\t;')]
     c = collections.Counter(ins)
