@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_deep(FrameArg
     Ctr ctr;
     uint32_t n_ranges = 0;   // (the same in every lane)
     bool counted = false;    // this wave is one of ctl.active: it holds rays, or is fetching some
-    uint32_t n_refl = 0, n_refr = 0, deepest = 0, idle_polls = 0;
+    uint32_t n_refl = 0, n_refr = 0, deepest = 0, idle_polls = 0, empty_looks = 0;
     for (;;) {
         // ---- the next batch: up to 64 nodes
         uint32_t node = NONE;
@@ -537,6 +537,10 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_deep(FrameArg
                 const uint32_t others = lds_peek(&ctl.active);
                 const uint32_t left = lds_peek(&ctl.top);
                 if (others == 0u && left == 0u) break;
+                // The rays of a block dwindle from level to level, and so does the number of waves they need: a
+                // wave that has found nothing a few times running leaves for good (its slot to another frame's
+                // kernel); the waves that hold rays take care of what those spawn.
+                if (left == 0u && A.deep_exit_polls != 0u && ++empty_looks >= A.deep_exit_polls) break;
                 if (++idle_polls > (1u << 18)) { atomicMax(A.overflow, DEEP_STUCK + 3u); break; }
                 __builtin_amdgcn_s_sleep(32);
                 continue;
@@ -1240,9 +1244,9 @@ bool can_fuse(const FrameArgs& A, uint32_t last_level) {
     return RT_FUSE_DEEP != 0 && A.scene.lean != 0 && g_lean_stays[1] && last_level >= 2u && A.max_depth <= DEEP_MAX_LEVEL;
 }
 
-hipError_t launch_deep(const FrameArgs& A, uint32_t grid, hipStream_t st, int* variant) {
+hipError_t launch_deep(const FrameArgs& A, uint32_t grid, uint32_t per_cu, hipStream_t st, int* variant) {
     const uint32_t tb = g_deep_block;
-    const dim3 g(blocks_of(grid, tb, true, RT_LEAN_BLOCKS_PER_CU)), b(tb);
+    const dim3 g(blocks_of(grid, tb, true, per_cu != 0u && per_cu < RT_LEAN_BLOCKS_PER_CU ? per_cu : RT_LEAN_BLOCKS_PER_CU)), b(tb);
     const size_t lds = stack_bytes(A.scene, true, tb, true);
     if (variant) *variant = LEAN_ID + 32;  // (+ 32: all deeper levels in one launch)
     hipLaunchKernelGGL((k_deep<LEAN_ID, NoCounters>), g, b, lds, st, A);

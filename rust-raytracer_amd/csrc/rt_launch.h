@@ -102,6 +102,7 @@ struct FrameArgs {
     // a node's level is kept in node_kid.w >> 1.
     uint32_t fused;
     uint32_t* deep_max;     // fused: the deepest level that held a ray
+    uint32_t deep_exit_polls;  // fused: looks at an empty stack after which an idle wave of k_deep leaves for good (0: it stays to the end)
     // shadow-ray queue of the frame
     float4* sray_o;         // origin.xyz, distance to the light
     float4* sray_d;         // direction.xyz, bits(ignored primitive)
@@ -132,7 +133,7 @@ struct DeinterleaveArgs {
     hipError_t launch_intersect(const rtamd::FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant); \
     hipError_t launch_shadow(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work, bool cull, \
                              uint32_t grid, hipStream_t st, int* variant);                                           \
-    hipError_t launch_deep(const rtamd::FrameArgs& A, uint32_t grid, hipStream_t st, int* variant);                  \
+    hipError_t launch_deep(const rtamd::FrameArgs& A, uint32_t grid, uint32_t per_cu, hipStream_t st, int* variant); \
     bool can_fuse(const rtamd::FrameArgs& A, uint32_t last_level);                                                   \
     hipError_t launch_light(const rtamd::FrameArgs& A, uint32_t first_level, uint32_t last_level, bool work,         \
                             uint32_t grid, hipStream_t st);                                                          \
