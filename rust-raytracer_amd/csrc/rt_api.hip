@@ -160,7 +160,9 @@ struct rt_context {
     // size launches per level.  Only a hint -- every kernel strides over its level whatever the grid.
     uint64_t hint_scene = 0;  // rt_scene::serial (a number, not an address: a scene created where a destroyed one lay is another scene)
     uint32_t hint_slots = 0, hint_depth = 0;
-    uint32_t hint_rays[RT_MAX_LEVELS] = {}, hint_lit[RT_MAX_LEVELS] = {};
+    // ([1]: of frames whose deeper levels ran as one launch -- there "level 2" stands for all levels from 2 on)
+    uint32_t hint_rays[2][RT_MAX_LEVELS] = {}, hint_lit[2][RT_MAX_LEVELS] = {};
+    bool hint_valid[2] = {false, false};
 };
 
 static std::atomic<uint64_t> g_scene_serial{0};
@@ -853,22 +855,6 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // rays need (a quarter more, at least one block per CU) instead of the most it could need:
     // the blocks past a level's end only start, read the level's size and leave, but there are
     // tens of thousands of them per launch and they hold wave slots while they do.
-    const bool hinted = ctx->hint_scene == scene->serial && ctx->hint_slots == n_slots && ctx->hint_depth == opt->max_depth;
-    auto blocks_for = [&](uint64_t rays, uint32_t most) -> uint32_t {
-        if (!hinted) return most;
-        const uint64_t b = (rays + (rays >> 2) + RT_BLOCK - 1) / RT_BLOCK;
-        return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(b, 256));
-    };
-    auto shadow_rays = [&](uint32_t first, uint32_t last) -> int {
-        uint64_t lit = 0;
-        for (uint32_t l = first; l <= last; ++l) lit += ctx->hint_lit[l];
-        const uint32_t gs = blocks_for(lit, first == 0 ? grids : gridn);
-        RT_HIP(ctx, hipStreamWaitEvent(st2, f.ev_level[last], 0));
-        RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2, &f.variant_shadow)
-                         : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2, &f.variant_shadow));
-        return RT_OK;
-    };
-    bool lit_level0 = false;  // level 0's lighting is queued already
     // All levels below the camera rays in one launch, where the kernels for that exist (lean scenes): the
     // frame is then level 0, that launch, and the shadow rays of both.  It shortens a frame (balls at
     // 3840x2160: the deeper levels 1.63 -> 1.13 ms, one frame at a time 5.21 -> 4.96 ms, an eighth of the
@@ -877,6 +863,23 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // against 4.72 with four in flight).
     const bool fused = !work && cull && ctx->fuse_deep && !(f.one_stream && !serial) &&
                        (fast ? rt_fast::can_fuse(A, last_level) : rt_exact::can_fuse(A, last_level));
+    const int hm = fused ? 1 : 0;  // which set of level sizes applies
+    const bool hinted = ctx->hint_valid[hm] && ctx->hint_scene == scene->serial && ctx->hint_slots == n_slots && ctx->hint_depth == opt->max_depth;
+    auto blocks_for = [&](uint64_t rays, uint32_t most) -> uint32_t {
+        if (!hinted) return most;
+        const uint64_t b = (rays + (rays >> 2) + RT_BLOCK - 1) / RT_BLOCK;
+        return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(b, 256));
+    };
+    auto shadow_rays = [&](uint32_t first, uint32_t last) -> int {
+        uint64_t lit = 0;
+        for (uint32_t l = first; l <= last; ++l) lit += ctx->hint_lit[hm][l];
+        const uint32_t gs = blocks_for(lit, first == 0 ? grids : gridn);
+        RT_HIP(ctx, hipStreamWaitEvent(st2, f.ev_level[last], 0));
+        RT_HIP(ctx, fast ? rt_fast::launch_shadow(A, first, last, work, cull, gs, st2, &f.variant_shadow)
+                         : rt_exact::launch_shadow(A, first, last, work, cull, gs, st2, &f.variant_shadow));
+        return RT_OK;
+    };
+    bool lit_level0 = false;  // level 0's lighting is queued already
     A.fused = fused ? 1u : 0u;
     f.fused = fused;
     if (fused) {
@@ -892,7 +895,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
             }
         }
         // (blocks stay and take rays from the launch's counter: as many as the level-1 rays can use)
-        const uint32_t gd = blocks_for(ctx->hint_rays[1], gridn);
+        const uint32_t gd = blocks_for(ctx->hint_rays[hm][1], gridn);
         RT_HIP(ctx, fast ? rt_fast::launch_deep(A, gd, 0u, st, &f.variant_deep) : rt_exact::launch_deep(A, gd, 0u, st, &f.variant_deep));
         if (serial) {
             RT_HIP(ctx, hipEventRecord(f.ev_t[1], st));
@@ -906,7 +909,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         }
     }
     for (uint32_t level = 0; level <= last_level && !fused; ++level) {
-        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[level], gridn);
+        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[hm][level], gridn);
         int* variant = level > 0 ? &f.variant_deep : nullptr;
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st, variant) : rt_exact::launch_intersect(A, level, work, cull, g, st, variant));
         if (serial) {
@@ -942,7 +945,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
         {   // direct light of every node of the frame, once all shadow rays are traced: one launch, and
             // no level's shadow rays wait behind an earlier level's lighting
             uint64_t rays = lit_level0 ? 0u : n_slots;
-            for (uint32_t l = 1; l <= last_level; ++l) rays += ctx->hint_rays[l];
+            for (uint32_t l = 1; l <= last_level; ++l) rays += ctx->hint_rays[hm][l];
             const uint32_t gl = hinted ? blocks_for(rays, 0x7fffffffu) : grid0 + gridn;
             const uint32_t from = lit_level0 ? 1u : 0u;
             RT_HIP(ctx, fast ? rt_fast::launch_light(A, from, last_level, work, gl, st2)
@@ -955,7 +958,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     RT_HIP(ctx, hipEventRecord(f.ev[1], st));
     for (uint32_t level = last_level + 1; level-- > 0;) {
         // (fused: hint_rays[2] is the size of the range all levels from 2 on share, which each of their launches goes over)
-        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[fused && level > 2 ? 2 : level], gridn);
+        const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[hm][fused && level > 2 ? 2 : level], gridn);
         if (level == 0) RT_HIP(ctx, hipStreamWaitEvent(st, f.ev_caller, 0));  // the caller's buffers are written from here on
         RT_HIP(ctx, fast ? rt_fast::launch_resolve(A, level, g, st) : rt_exact::launch_resolve(A, level, g, st));
     }
@@ -1021,12 +1024,16 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
             stats.work[k] = c[4 + k] + c[24 + k];
             stats.work_shadow[k] = c[24 + k];
         }
+        if (ctx->hint_scene != f.scene->serial || ctx->hint_slots != p.n_slots || ctx->hint_depth != opt->max_depth)
+            ctx->hint_valid[0] = ctx->hint_valid[1] = false;  // (another kind of frame: neither set of level sizes is its)
         ctx->hint_scene = f.scene->serial;
         ctx->hint_slots = p.n_slots;
         ctx->hint_depth = opt->max_depth;
+        const int hm = f.fused ? 1 : 0;
+        ctx->hint_valid[hm] = true;
         for (uint32_t l = 0; l < RT_MAX_LEVELS; ++l) {
-            ctx->hint_rays[l] = l <= opt->max_depth ? lv[l] : 0u;
-            ctx->hint_lit[l] = l <= opt->max_depth ? lv[LV_SHADOW_COUNT + l] : 0u;
+            ctx->hint_rays[hm][l] = l <= opt->max_depth ? lv[l] : 0u;
+            ctx->hint_lit[hm][l] = l <= opt->max_depth ? lv[LV_SHADOW_COUNT + l] : 0u;
         }
         stats.kernel_shadow = f.variant_shadow;
         stats.kernel_deep = f.variant_deep;

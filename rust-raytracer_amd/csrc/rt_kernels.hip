@@ -414,9 +414,14 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
 // are used up, waves take what the stack holds, however little; a block is done when its stack is empty
 // and none of its waves holds rays.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t DEEP_STACK = 2048u;        // node indices a block's stack holds
 constexpr uint32_t DEEP_MAX_LEVEL = 16u;      // deepest max_depth this kernel serves (per-wave ranges below)
-constexpr uint32_t DEEP_RANGES = 2u * DEEP_MAX_LEVEL + 8u;
+// Node indices a block's stack holds, and ranges a wave can keep (one per level and a few).  The blocks that
+// carry a copy of the node array (CULL + 16: 1024 threads, 152 KiB of stacks, lane words and nodes) have
+// room for less.
+template <int CULL> struct DeepRoom {
+    static constexpr uint32_t STACK = (CULL & 16) != 0 ? 1024u : 2048u;
+    static constexpr uint32_t RANGES = (CULL & 16) != 0 ? DEEP_MAX_LEVEL + 6u : 2u * DEEP_MAX_LEVEL + 8u;
+};
 constexpr uint32_t DEEP_KEEP = 48u;           // offspring of at least this many rays stays with its wave
 struct DeepCtl {
     uint32_t lock, top, active, level1_done;
@@ -452,8 +457,9 @@ template <int CULL, class Ctr>
 __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_deep(FrameArgs A) {
     extern __shared__ uint2 lds_stack[];
     __shared__ DeepCtl ctl;
+    constexpr uint32_t DEEP_STACK = DeepRoom<CULL>::STACK;
     __shared__ uint32_t q_idx[DEEP_STACK];
-    __shared__ uint2 q_ranges[RT_MAX_BLOCK_WAVES][DEEP_RANGES];  // per wave: {first node, count} of rays it keeps for itself
+    __shared__ uint2 q_ranges[RT_MAX_BLOCK_WAVES][DeepRoom<CULL>::RANGES];  // per wave: {first node, count} of rays it keeps for itself
 
     const DevScene& S = A.scene;
     const uint32_t base1 = A.level_base[1];
@@ -471,7 +477,9 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_deep(FrameArg
     uint2* const ranges = q_ranges[threadIdx.x >> 6];
     // (runs of level-1 rays per visit to the launch's counter: more on big levels, where one address would not
     // take an add per 64 rays fast enough)
-    const uint32_t take1 = count1 >= (1u << 22) ? LEAN_TAKE : 64u;
+    // (lean scenes only: elsewhere a ray takes ten times as long, and runs of 512 would leave the last waves long tails)
+    const uint32_t take1 = ((CULL & 4) != 0 && count1 >= (1u << 22)) ? LEAN_TAKE : 64u;
+    const uint32_t plenty = 32u * (blockDim.x >> 6);  // rays on the stack from which the block's other waves are served well enough
     Ctr ctr;
     uint32_t n_ranges = 0;   // (the same in every lane)
     bool counted = false;    // this wave is one of ctl.active: it holds rays, or is fetching some
@@ -619,7 +627,9 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_deep(FrameArg
         if (n_kids != 0u) {
             // (the rays just written are read back by this wave or by another of the block)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            bool kept = n_kids >= DEEP_KEEP;
+            // A full batch stays with its wave, unless the stack is low: then the block's idle waves need it more
+            // (a wave that kept all its rays' offspring to itself would walk a whole sub-tree alone).
+            bool kept = n_kids >= DEEP_KEEP && lds_peek(&ctl.top) >= plenty;
             if (!kept) {
                 if (!deep_lock(&ctl)) { atomicMax(A.overflow, DEEP_STUCK + 4u); break; }
                 const uint32_t top = ctl.top;
@@ -1110,7 +1120,7 @@ static const bool g_lean_stays[5] = {RT_STAY_LEVEL0 != 0, RT_STAY_DEEP != 0, RT_
 // Threads per staying block of each lean kernel: RT_LEAN_BLOCKS_PER_CU blocks fill the waves per SIMD the
 // kernel's register use allows (init_kernels).  [0] k_intersect level 0, [1] deeper levels, [2..4] k_shadow by mode.
 static uint32_t g_lean_block[5] = {512, 512, 512, 512, 512};
-static uint32_t g_deep_block = 512;  // the same for k_deep
+static uint32_t g_deep_block[3] = {512, 512, 1024};  // the same for k_deep: lean scenes, the others, those with the nodes in LDS (one block per CU)
 // The same for the staying blocks of scenes that are not lean, one block per CU: [0] k_intersect level 0,
 // [1] deeper levels, [2] k_shadow (mode 0); [0] unused.
 static uint32_t g_gen_block[3] = {1024, 1024, 1024};
@@ -1155,7 +1165,7 @@ hipError_t init_kernels() {
                          (const void*)k_shadow<2, NoCounters, 1>, (const void*)k_shadow<LEAN_SH, NoCounters, 1>,
                          (const void*)k_shadow<2, NoCounters, 2>, (const void*)k_shadow<LEAN_SH, NoCounters, 2>,
                          (const void*)k_intersect<false, GEN_ID, NoCounters>, (const void*)k_shadow<GEN_SH, NoCounters>,
-                         (const void*)k_deep<LEAN_ID, NoCounters>,
+                         (const void*)k_deep<LEAN_ID, NoCounters>, (const void*)k_deep<2, NoCounters>, (const void*)k_deep<GEN_ID, NoCounters>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
     for (const void* f : fns) {
         hipFuncAttributes fa;
@@ -1180,16 +1190,17 @@ hipError_t init_kernels() {
         if (threads > RT_LEAN_BLOCK) threads = RT_LEAN_BLOCK;
         g_lean_block[k] = threads < 64u ? 64u : threads;
     }
-    {
+    const void* deep_fns[3] = {(const void*)k_deep<LEAN_ID, NoCounters>, (const void*)k_deep<2, NoCounters>, (const void*)k_deep<GEN_ID, NoCounters>};
+    for (int k = 0; k < 3; ++k) {
         hipFuncAttributes fa;
-        hipError_t e = hipFuncGetAttributes(&fa, (const void*)k_deep<LEAN_ID, NoCounters>);
+        hipError_t e = hipFuncGetAttributes(&fa, deep_fns[k]);
         if (e != hipSuccess) return e;
         const uint32_t regs = ((uint32_t)(fa.numRegs > 0 ? fa.numRegs : 128) + 7u) & ~7u;
         uint32_t waves = 512u / regs;
         waves = waves < 1u ? 1u : (waves > 8u ? 8u : waves);
-        uint32_t threads = waves * 4u * 64u / RT_LEAN_BLOCKS_PER_CU;
+        uint32_t threads = waves * 4u * 64u / (k == 2 ? 1u : RT_LEAN_BLOCKS_PER_CU);
         if (threads > RT_LEAN_BLOCK) threads = RT_LEAN_BLOCK;
-        g_deep_block = threads < 64u ? 64u : threads;
+        g_deep_block[k] = threads < 64u ? 64u : threads;
     }
     const void* gen_fns[3] = {nullptr, (const void*)k_intersect<false, GEN_ID, NoCounters>, (const void*)k_shadow<GEN_SH, NoCounters>};
     for (int k = 1; k < 3; ++k) {
@@ -1240,16 +1251,25 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
 #ifndef RT_FUSE_DEEP
 #define RT_FUSE_DEEP 1
 #endif
+#ifndef RT_FUSE_DEEP_GENERAL
+#define RT_FUSE_DEEP_GENERAL 1
+#endif
 bool can_fuse(const FrameArgs& A, uint32_t last_level) {
-    return RT_FUSE_DEEP != 0 && A.scene.lean != 0 && g_lean_stays[1] && last_level >= 2u && A.max_depth <= DEEP_MAX_LEVEL;
+    if (RT_FUSE_DEEP == 0 || last_level < 2u || A.max_depth > DEEP_MAX_LEVEL) return false;
+    return A.scene.lean != 0 ? g_lean_stays[1] : RT_FUSE_DEEP_GENERAL != 0;
 }
 
 hipError_t launch_deep(const FrameArgs& A, uint32_t grid, uint32_t per_cu, hipStream_t st, int* variant) {
-    const uint32_t tb = g_deep_block;
-    const dim3 g(blocks_of(grid, tb, true, per_cu != 0u && per_cu < RT_LEAN_BLOCKS_PER_CU ? per_cu : RT_LEAN_BLOCKS_PER_CU)), b(tb);
-    const size_t lds = stack_bytes(A.scene, true, tb, true);
-    if (variant) *variant = LEAN_ID + 32;  // (+ 32: all deeper levels in one launch)
-    hipLaunchKernelGGL((k_deep<LEAN_ID, NoCounters>), g, b, lds, st, A);
+    const bool lean = A.scene.lean != 0;
+    const bool lds_nodes = !lean && A.scene.nodes_lds != 0u && RT_STAY_GEN_DEEP != 0;  // (small trees: a copy of the nodes in every block)
+    const uint32_t tb = g_deep_block[lean ? 0 : (lds_nodes ? 2 : 1)];
+    const uint32_t most = lds_nodes ? 1u : RT_LEAN_BLOCKS_PER_CU;
+    const dim3 g(blocks_of(grid, tb, true, per_cu != 0u && per_cu < most ? per_cu : most)), b(tb);
+    const size_t lds = stack_bytes(A.scene, lean, tb, lean || lds_nodes);
+    if (variant) *variant = (lean ? LEAN_ID : (lds_nodes ? GEN_ID : 2)) + 32;  // (+ 32: all deeper levels in one launch)
+    if (lean) hipLaunchKernelGGL((k_deep<LEAN_ID, NoCounters>), g, b, lds, st, A);
+    else if (lds_nodes) hipLaunchKernelGGL((k_deep<GEN_ID, NoCounters>), g, b, lds, st, A);
+    else hipLaunchKernelGGL((k_deep<2, NoCounters>), g, b, lds, st, A);
     return hipGetLastError();
 }
 

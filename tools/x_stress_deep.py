@@ -7,7 +7,8 @@ rtamd = importlib.import_module("rust-raytracer_amd")
 spd = importlib.import_module("rust-raytracer_amd.spd")
 from conftest import read_nff
 ctx = rtamd.Context(0)
-texts = [read_nff("extra-glass"), read_nff("test-square"), spd.balls(2, 64, 64).encode(), read_nff("test-sphere"), spd.balls(3, 64, 64).encode()]
+texts = [read_nff("extra-glass"), read_nff("test-square"), spd.balls(2, 64, 64).encode(), read_nff("test-sphere"), spd.balls(3, 64, 64).encode(),
+         read_nff("extra-cones"), spd.rings(2, 64, 64).encode(), spd.mount(4, 2, 64, 64).encode(), read_nff("extra-onplane"), spd.lathe(24, 12, 64, 64).encode()]
 n_fail = 0
 t0 = time.time()
 stream = torch.cuda.current_stream().cuda_stream
