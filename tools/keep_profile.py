@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Copies the summaries tools/r2_profile.sh left under gpurun_out/prof_<tag>/ (and the two bench lines beside it)
+"""Copies the summaries tools/r3_profile.sh left under gpurun_out/prof_<tag>/ (and the two bench lines beside it)
 into profiles/<round>/ under the workload's name, stamping the traffic file with the commit the library was built
 from (HEAD; refuses if the kernel sources differ from it).
-usage: tools/keep_profile.py <tag> <workload name, e.g. balls4k_depth8_exact> [round directory, default r02]"""
+usage: tools/keep_profile.py <tag> <workload name, e.g. balls4k_depth8_exact> [round directory, default r03]"""
 import json, os, shutil, subprocess, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
-rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
 dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "rust-raytracer_amd/csrc", "include", "bench.py"],
                        capture_output=True, text=True).stdout.strip()
 if dirty:

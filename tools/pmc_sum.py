@@ -49,7 +49,7 @@ def main():
                          "frames' kernels, FETCH_SIZE x 2 (gfx950), / frames"}
         # per launch, for the kernels of the timed frames (meaningful for a run on the serial schedule,
         # where a frame launches each of them a fixed number of times)
-        names = {"k_shadow": "k_shadow<", "k_intersect0": "k_intersect<true", "k_intersect_deep": "k_intersect<false",
+        names = {"k_shadow": "k_shadow<", "k_intersect0": "k_intersect<true", "k_intersect_deep": "k_intersect<false", "k_deep": "k_deep<",
                  "k_light": "k_light<", "k_resolve0": "k_resolve<true", "k_resolve_deep": "k_resolve<false"}
         for label, needle in names.items():
             f_sum = w_sum = 0.0
