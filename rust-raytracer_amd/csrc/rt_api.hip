@@ -181,7 +181,8 @@ struct rt_scene {
     DevBuf<uint2> sph_id;
     DevBuf<float> bnd;
     DevBuf<float4> cones, poly_rec, poly_bound, cone_bound, vpos, vnrm, surfaces, lights;
-    DevBuf<uint32_t> prim_surface;
+    DevBuf<uint32_t> prim_surface, prim_entry;
+    DevBuf<float4> prim_box;
     DevScene dev{};
 };
 
@@ -208,6 +209,7 @@ int fail(rt_context* ctx, int code, const std::string& msg) {
     } while (0)
 
 float4 f4(const float* v, float w) { return make_float4(v[0], v[1], v[2], w); }
+float comp4(const float4& v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
 float bits_to_float(uint32_t u) {
     float f;
     memcpy(&f, &u, 4);
@@ -500,24 +502,14 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         to.push_back(make_float4(rec[0], rec[1], rec[2], rec[3]));
     };
     bool any_poly_walk = false;
-    for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
-        const rt_kd_node& n = sc->tree.nodes[ni];
-        if (n.axis != 3) {  // {plane, axis, under, over} + the children's boxes
-            const rt_kd_node& u = sc->tree.nodes[n.under];
-            const rt_kd_node& o = sc->tree.nodes[n.over];
-            auto fb = [](float f) { uint32_t b; memcpy(&b, &f, 4); return b; };
-            nodes[ni * 4 + 0] = make_uint4(fb(n.plane), n.axis, n.under, n.over);
-            nodes[ni * 4 + 1] = make_uint4(fb(u.bmin[0]), fb(u.bmin[1]), fb(u.bmin[2]), fb(u.bmax[0]));
-            nodes[ni * 4 + 2] = make_uint4(fb(u.bmax[1]), fb(u.bmax[2]), fb(o.bmin[0]), fb(o.bmin[1]));
-            nodes[ni * 4 + 3] = make_uint4(fb(o.bmin[2]), fb(o.bmax[0]), fb(o.bmax[1]), fb(o.bmax[2]));
-            continue;
-        }
+    // One leaf's runs: `list` holds {primitive, position in the leaf's list}; returns the leaf record's words.
+    auto emit_leaf = [&](const std::vector<std::pair<uint32_t, uint32_t>>& list, uint4 rec[3]) {
         const uint32_t s0 = (uint32_t)sph.size(), p0 = (uint32_t)poly_items.size();
         std::vector<LeafSphere> ls, lp, lc;
         std::vector<uint4> true_cones;
         bool poly_bounds = true;
-        for (uint32_t k = 0; k < n.over; ++k) {
-            const uint32_t prim = sc->tree.refs[n.under + k];
+        for (const auto& pk : list) {
+            const uint32_t prim = pk.first, k = pk.second;
             const rt_primitive& p = sd.primitives[prim];
             if (p.kind == RT_KIND_SPHERE) {
                 const rt_sphere& s = sd.spheres[p.index];
@@ -566,9 +558,90 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             sph.push_back(make_float4(e.c[0], e.c[1], e.c[2], e.r * e.r));  // src/sphere.rs:53
             sph_id.push_back(make_uint2(e.prim, e.pos));
         }
-        nodes[ni * 4 + 0] = make_uint4(cu0, 3u, 0u, 0u);
-        nodes[ni * 4 + 1] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
-        nodes[ni * 4 + 2] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, pu0);
+        rec[0] = make_uint4(cu0, 3u, 0u, 0u);
+        rec[1] = make_uint4(s0, ns, c0, (uint32_t)cone_items.size() - c0);
+        rec[2] = make_uint4(p0, (uint32_t)poly_items.size() - p0, u0, pu0);
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> leaf_list;
+    for (size_t ni = 0; ni < sc->tree.nodes.size(); ++ni) {
+        const rt_kd_node& n = sc->tree.nodes[ni];
+        if (n.axis != 3) {  // {plane, axis, under, over} + the children's boxes
+            const rt_kd_node& u = sc->tree.nodes[n.under];
+            const rt_kd_node& o = sc->tree.nodes[n.over];
+            auto fb = [](float f) { uint32_t b; memcpy(&b, &f, 4); return b; };
+            nodes[ni * 4 + 0] = make_uint4(fb(n.plane), n.axis, n.under, n.over);
+            nodes[ni * 4 + 1] = make_uint4(fb(u.bmin[0]), fb(u.bmin[1]), fb(u.bmin[2]), fb(u.bmax[0]));
+            nodes[ni * 4 + 2] = make_uint4(fb(u.bmax[1]), fb(u.bmax[2]), fb(o.bmin[0]), fb(o.bmin[1]));
+            nodes[ni * 4 + 3] = make_uint4(fb(o.bmin[2]), fb(o.bmax[0]), fb(o.bmax[1]), fb(o.bmax[2]));
+            continue;
+        }
+        leaf_list.clear();
+        for (uint32_t k = 0; k < n.over; ++k) leaf_list.emplace_back(sc->tree.refs[n.under + k], k);
+        emit_leaf(leaf_list, &nodes[ni * 4]);
+    }
+    const bool lean_scene = cone_items.empty() && !any_poly_walk && poly_items.size() <= 8;  // (what the real leaves hold)
+
+    // The hit-list walk (rt_traverse.h, HitWalk) needs: every primitive once, as one more "leaf" whose list
+    // is the scene's (a leaf's list is a sub-sequence of it, src/space_partition.rs:160-169, so the position
+    // there orders two primitives as any leaf's list does); each primitive's box as split() read it
+    // (:163-166: corner, fl(corner + extent)); where a primitive's entry lies in that leaf's runs; and the
+    // certainty that this partition's leaves ARE what split() makes of those boxes (a partition the caller
+    // handed in need not be).
+    uint4 all_rec[3] = {make_uint4(0xffffffffu, 3u, 0u, 0u), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0xffffffffu)};
+    std::vector<float4> pboxes;
+    std::vector<uint32_t> prim_entry;
+    bool hit_walk = !lean_scene && sd.primitives.size() > 0 && sd.primitives.size() < (1u << 29) &&
+                    sc->tree.nodes.size() < (1u << HITWALK_NODE_BITS);
+    if (const char* e = getenv("RTAMD_HIT_WALK")) hit_walk = hit_walk && atoi(e) != 0;
+    if (hit_walk) {
+        const uint32_t np = (uint32_t)sd.primitives.size();
+        pboxes.resize((size_t)np * 2);
+        for (uint32_t i = 0; i < np; ++i) {
+            float c[3], e[3];
+            prim_box(sd.desc, i, c, e);
+            pboxes[i * 2] = make_float4(c[0], c[1], c[2], 0.0f);
+            pboxes[i * 2 + 1] = make_float4(c[0] + e[0], c[1] + e[1], c[2] + e[2], 0.0f);
+        }
+        // the leaves follow from the boxes and the planes?
+        std::vector<std::pair<uint32_t, std::vector<uint32_t>>> todo;
+        {
+            std::vector<uint32_t> all(np);
+            for (uint32_t i = 0; i < np; ++i) all[i] = i;
+            todo.emplace_back(0u, std::move(all));
+        }
+        while (hit_walk && !todo.empty()) {
+            const uint32_t ni = todo.back().first;
+            const std::vector<uint32_t> list = std::move(todo.back().second);
+            todo.pop_back();
+            const rt_kd_node& n = sc->tree.nodes[ni];
+            if (n.axis == 3) {
+                hit_walk = n.over == list.size() && (list.empty() || memcmp(&sc->tree.refs[n.under], list.data(), list.size() * sizeof(uint32_t)) == 0);
+                continue;
+            }
+            if (n.axis > 2) { hit_walk = false; break; }
+            std::vector<uint32_t> under, over;
+            for (uint32_t p : list) {  // src/space_partition.rs:160-169
+                if (comp4(pboxes[p * 2 + 1], n.axis) > n.plane) over.push_back(p);
+                if (comp4(pboxes[p * 2], n.axis) <= n.plane) under.push_back(p);
+            }
+            todo.emplace_back(n.over, std::move(over));
+            todo.emplace_back(n.under, std::move(under));
+        }
+    }
+    if (hit_walk) {
+        leaf_list.clear();
+        for (uint32_t i = 0; i < (uint32_t)sd.primitives.size(); ++i) leaf_list.emplace_back(i, i);
+        const size_t s_from = sph_id.size(), c_from = cone_items.size(), p_from = poly_items.size();
+        emit_leaf(leaf_list, all_rec);
+        prim_entry.assign(sd.primitives.size(), 0xffffffffu);
+        for (size_t i = s_from; i < sph_id.size(); ++i)
+            if ((sph_id[i].y >> 31) == 0u) prim_entry[sph_id[i].x] = (uint32_t)i;  // (not the padding copies)
+        for (size_t i = c_from; i < cone_items.size(); ++i)
+            if ((cone_items[i].y >> 31) == 0u) prim_entry[cone_items[i].x] = (uint32_t)i | (1u << 30);
+        for (size_t i = p_from; i < poly_items.size(); ++i)
+            if ((poly_items[i].y >> 31) == 0u) prim_entry[poly_items[i].x] = (uint32_t)i | (2u << 30);
+        for (uint32_t e : prim_entry)
+            if (e == 0xffffffffu || (e & 0x3fffffffu) >= (1u << 29)) hit_walk = false;
     }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;
@@ -623,6 +696,10 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     RT_HIP(ctx, sc->surfaces.upload(surfaces));
     RT_HIP(ctx, sc->lights.upload(lights));
     RT_HIP(ctx, sc->prim_surface.upload(prim_surface));
+    if (hit_walk) {
+        RT_HIP(ctx, sc->prim_box.upload(pboxes));
+        RT_HIP(ctx, sc->prim_entry.upload(prim_entry));
+    }
 
     DevScene& d = sc->dev;
     d.nodes = sc->nodes.p;
@@ -643,9 +720,15 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
     // lean: no cones and next to no polygons (a floor): kernels without the code for either's records
     d.bnd_records = (uint32_t)(bnd.size() / 4);
-    d.lean = (cone_items.empty() && !any_poly_walk && poly_items.size() <= 8 && d.stack_depth <= RT_STACK_RING &&
+    d.lean = (lean_scene && d.stack_depth <= RT_STACK_RING &&
               bnd.size() * sizeof(float) <= RT_LEAN_RECORD_BYTES) ? 1u : 0u;
     d.n_nodes = (uint32_t)sc->tree.nodes.size();
+    d.hit_walk = hit_walk ? 1u : 0u;
+    d.prim_box = sc->prim_box.p;
+    d.prim_entry = sc->prim_entry.p;
+    d.all_w = all_rec[0].x;
+    d.all_q2 = all_rec[1];
+    d.all_q3 = all_rec[2];
     d.nodes_lds = (d.lean == 0u && (size_t)d.n_nodes * 64u <= RT_NODE_LDS_BYTES) ? 1u : 0u;
     // Measured at 3840x2160 (k_shadow, ms, lanes waiting for their wave / lanes taking the next ray): rings 4
     // (largest leaf 212) 23.1 / 18.4; lathe 96 at 1920x1080 (273) 2.41 / 2.34; mount 8 (45685) 6.4 / 8.0;

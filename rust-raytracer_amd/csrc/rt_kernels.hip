@@ -689,9 +689,14 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
         const float4 sd = A.sray_d[i];
         Hit blocker;
         bool blocked = false;
-        if (kd_traverse_closest<CULL, Ctr, OCC>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w),
-                                                blocker, lds_stack, ctr, so.w))
-            blocked = blocker.dist <= so.w;
+        bool found;
+        if constexpr ((CULL & 64) != 0)
+            found = kd_traverse_hits<CULL & 3, true>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
+                                                     lds_stack, ctr, so.w);
+        else
+            found = kd_traverse_closest<CULL, Ctr, OCC>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w),
+                                                        blocker, lds_stack, ctr, so.w);
+        if (found) blocked = blocker.dist <= so.w;
         A.sray_blocked[i] = blocked ? 1u : 0u;
     };
     // Position w of the launch's rays (light after light, `n` slots each) in the queue arrays.
@@ -704,7 +709,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
     // idle, which makes the fetch worth its instructions): in trees of small leaves rays differ widely
     // in the number of rounds they take, and a lane that waited for the slowest of its 64 would idle
     // half the time.  (A run of 64 rays is a wave that traces 64 rays and is done.)
-    auto trace_run = [&](KdWalk<CULL, Ctr, OCC>& w, uint32_t c0, uint32_t c_end, uint64_t queue, bool linear) {
+    auto trace_run = [&](KdWalk<CULL & ~64, Ctr, OCC>& w, uint32_t c0, uint32_t c_end, uint64_t queue, bool linear) {
         uint32_t next = c0;
         bool have = false;
         uint64_t mine = 0;
@@ -747,7 +752,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
         if (block_late(next, total, &late_flag)) return;
         stage_scene<CULL>(S, lds_stack);
         KdDeep<!LEAN> deep;
-        KdWalk<CULL, Ctr, OCC> w(S, lds_stack, ctr, deep);
+        KdWalk<CULL & ~64, Ctr, OCC> w(S, lds_stack, ctr, deep);
         for (;;) {
             uint32_t c = 0;
             if (lane_id() == 0) c = atomicAdd(next, LEAN_TAKE);
@@ -764,11 +769,11 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
                 for (uint32_t part = c; part < c_end; part += run) trace_run(w, part, run < c_end - part ? part + run : c_end, 0, true);
             }
         }
-    } else if constexpr (RT_SHADOW_REFILL != 0 && !LEAN) {
+    } else if constexpr (RT_SHADOW_REFILL != 0 && !LEAN && (CULL & 64) == 0) {
         const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
         const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
         KdDeep<!LEAN> deep;
-        KdWalk<CULL, Ctr, OCC> w(S, lds_stack, ctr, deep);
+        KdWalk<CULL & ~64, Ctr, OCC> w(S, lds_stack, ctr, deep);
         for (uint64_t c0 = (uint64_t)first + (uint64_t)wave * chunk; c0 < end; c0 += (uint64_t)n_waves * chunk)
             trace_run(w, (uint32_t)c0, c0 + chunk < end ? (uint32_t)c0 + chunk : end, queue, false);
     } else {
@@ -1115,12 +1120,13 @@ static uint32_t g_cus = 256;  // compute units of the device (init_kernels)
 #define RT_STAY_GEN_SHADOW 1
 #endif
 constexpr int GEN_ID = 2 | 8 | 16, GEN_SH = 2 | 8 | 16;
+constexpr int HITS_ID = 2 | 64, HITS_SH = 2 | 64;  // the hit-list walk (DevScene::hit_walk): deeper levels, shadow rays
 constexpr int LEAN_I0 = 5 | (RT_STAY_LEVEL0 ? 8 : 0), LEAN_ID = 6 | (RT_STAY_DEEP ? 8 : 0), LEAN_SH = 6 | (RT_STAY_SHADOW ? 8 : 0);
 static const bool g_lean_stays[5] = {RT_STAY_LEVEL0 != 0, RT_STAY_DEEP != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0};
 // Threads per staying block of each lean kernel: RT_LEAN_BLOCKS_PER_CU blocks fill the waves per SIMD the
 // kernel's register use allows (init_kernels).  [0] k_intersect level 0, [1] deeper levels, [2..4] k_shadow by mode.
 static uint32_t g_lean_block[5] = {512, 512, 512, 512, 512};
-static uint32_t g_deep_block[3] = {512, 512, 1024};  // the same for k_deep: lean scenes, the others, those with the nodes in LDS (one block per CU)
+static uint32_t g_deep_block[4] = {512, 512, 1024, 512};  // the same for k_deep: lean scenes, the others, those with the nodes in LDS (one block per CU)
 // The same for the staying blocks of scenes that are not lean, one block per CU: [0] k_intersect level 0,
 // [1] deeper levels, [2] k_shadow (mode 0); [0] unused.
 static uint32_t g_gen_block[3] = {1024, 1024, 1024};
@@ -1166,7 +1172,10 @@ hipError_t init_kernels() {
                          (const void*)k_shadow<2, NoCounters, 2>, (const void*)k_shadow<LEAN_SH, NoCounters, 2>,
                          (const void*)k_intersect<false, GEN_ID, NoCounters>, (const void*)k_shadow<GEN_SH, NoCounters>,
                          (const void*)k_deep<LEAN_ID, NoCounters>, (const void*)k_deep<2, NoCounters>, (const void*)k_deep<GEN_ID, NoCounters>,
-                         (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>};
+                         (const void*)k_intersect<false, HITS_ID, NoCounters>, (const void*)k_intersect<false, HITS_ID, WorkCounters>,
+                         (const void*)k_shadow<HITS_SH, NoCounters>, (const void*)k_shadow<HITS_SH, WorkCounters>,
+                         (const void*)k_deep<HITS_ID, NoCounters>,
+                         (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>, (const void*)k_debug_intersect<HITS_ID>};
     for (const void* f : fns) {
         hipFuncAttributes fa;
         hipError_t e = hipFuncGetAttributes(&fa, f);  // (the kernel's own static LDS counts against the same 160 KiB)
@@ -1190,8 +1199,9 @@ hipError_t init_kernels() {
         if (threads > RT_LEAN_BLOCK) threads = RT_LEAN_BLOCK;
         g_lean_block[k] = threads < 64u ? 64u : threads;
     }
-    const void* deep_fns[3] = {(const void*)k_deep<LEAN_ID, NoCounters>, (const void*)k_deep<2, NoCounters>, (const void*)k_deep<GEN_ID, NoCounters>};
-    for (int k = 0; k < 3; ++k) {
+    const void* deep_fns[4] = {(const void*)k_deep<LEAN_ID, NoCounters>, (const void*)k_deep<2, NoCounters>, (const void*)k_deep<GEN_ID, NoCounters>,
+                               (const void*)k_deep<HITS_ID, NoCounters>};  // ([3]: the hit-list walk)
+    for (int k = 0; k < 4; ++k) {
         hipFuncAttributes fa;
         hipError_t e = hipFuncGetAttributes(&fa, deep_fns[k]);
         if (e != hipSuccess) return e;
@@ -1220,14 +1230,15 @@ hipError_t init_kernels() {
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant) {
     const bool lean = A.scene.lean != 0;
     const uint32_t which = level == 0 ? 0u : 1u;
-    const bool gen_stays = !work && cull && !lean && A.scene.nodes_lds != 0u && level > 0 && RT_STAY_GEN_DEEP != 0;
+    const bool hit_walk = cull && !lean && A.scene.hit_walk != 0u && level > 0;
+    const bool gen_stays = !work && cull && !lean && !hit_walk && A.scene.nodes_lds != 0u && level > 0 && RT_STAY_GEN_DEEP != 0;
     const bool stays = gen_stays || (!work && cull && lean && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
     const dim3 g(blocks_of(grid, tb, stays, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU)), b(tb);
     const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays);
     if (variant) {
         if (level == 0) *variant = !cull ? 0 : (!work && lean ? LEAN_I0 : 1);
-        else *variant = !cull ? 0 : (work ? 2 : (lean ? LEAN_ID : (gen_stays ? GEN_ID : 2)));
+        else *variant = !cull ? 0 : (hit_walk ? HITS_ID : (work ? 2 : (lean ? LEAN_ID : (gen_stays ? GEN_ID : 2))));
     }
     if (level == 0) {  // camera rays start outside the scene: the line test alone
         if (work && cull) hipLaunchKernelGGL((k_intersect<true, 1, WorkCounters>), g, b, lds, st, A, level);
@@ -1236,7 +1247,9 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
         else if (cull) hipLaunchKernelGGL((k_intersect<true, 1, NoCounters>), g, b, lds, st, A, level);
         else hipLaunchKernelGGL((k_intersect<true, 0, NoCounters>), g, b, lds, st, A, level);
     } else {
-        if (work && cull) hipLaunchKernelGGL((k_intersect<false, 2, WorkCounters>), g, b, lds, st, A, level);
+        if (work && hit_walk) hipLaunchKernelGGL((k_intersect<false, HITS_ID, WorkCounters>), g, b, lds, st, A, level);
+        else if (hit_walk) hipLaunchKernelGGL((k_intersect<false, HITS_ID, NoCounters>), g, b, lds, st, A, level);
+        else if (work && cull) hipLaunchKernelGGL((k_intersect<false, 2, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<false, 0, WorkCounters>), g, b, lds, st, A, level);
         else if (cull && lean) hipLaunchKernelGGL((k_intersect<false, LEAN_ID, NoCounters>), g, b, lds, st, A, level);
         else if (gen_stays) hipLaunchKernelGGL((k_intersect<false, GEN_ID, NoCounters>), g, b, lds, st, A, level);
@@ -1261,13 +1274,15 @@ bool can_fuse(const FrameArgs& A, uint32_t last_level) {
 
 hipError_t launch_deep(const FrameArgs& A, uint32_t grid, uint32_t per_cu, hipStream_t st, int* variant) {
     const bool lean = A.scene.lean != 0;
-    const bool lds_nodes = !lean && A.scene.nodes_lds != 0u && RT_STAY_GEN_DEEP != 0;  // (small trees: a copy of the nodes in every block)
-    const uint32_t tb = g_deep_block[lean ? 0 : (lds_nodes ? 2 : 1)];
+    const bool hit_walk = !lean && A.scene.hit_walk != 0u;
+    const bool lds_nodes = !lean && !hit_walk && A.scene.nodes_lds != 0u && RT_STAY_GEN_DEEP != 0;  // (small trees: a copy of the nodes in every block)
+    const uint32_t tb = g_deep_block[lean ? 0 : (hit_walk ? 3 : (lds_nodes ? 2 : 1))];
     const uint32_t most = lds_nodes ? 1u : RT_LEAN_BLOCKS_PER_CU;
     const dim3 g(blocks_of(grid, tb, true, per_cu != 0u && per_cu < most ? per_cu : most)), b(tb);
     const size_t lds = stack_bytes(A.scene, lean, tb, lean || lds_nodes);
-    if (variant) *variant = (lean ? LEAN_ID : (lds_nodes ? GEN_ID : 2)) + 32;  // (+ 32: all deeper levels in one launch)
+    if (variant) *variant = (lean ? LEAN_ID : (hit_walk ? HITS_ID : (lds_nodes ? GEN_ID : 2))) + 32;  // (+ 32: all deeper levels in one launch)
     if (lean) hipLaunchKernelGGL((k_deep<LEAN_ID, NoCounters>), g, b, lds, st, A);
+    else if (hit_walk) hipLaunchKernelGGL((k_deep<HITS_ID, NoCounters>), g, b, lds, st, A);
     else if (lds_nodes) hipLaunchKernelGGL((k_deep<GEN_ID, NoCounters>), g, b, lds, st, A);
     else hipLaunchKernelGGL((k_deep<2, NoCounters>), g, b, lds, st, A);
     return hipGetLastError();
@@ -1277,14 +1292,16 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
                          hipStream_t st, int* variant) {
     const bool lean_kernel = !work && cull && A.scene.lean != 0;
     const uint32_t which = 2u + (A.shadow_mode <= 2u ? A.shadow_mode : 0u);
-    const bool gen_stays = !work && cull && A.scene.lean == 0 && A.scene.nodes_lds != 0u && A.shadow_mode == 0u && RT_STAY_GEN_SHADOW != 0;
+    // (the hit-list walk gives the reference's answer: shadow modes 0 and 1)
+    const bool hit_walk = cull && A.scene.lean == 0 && A.scene.hit_walk != 0u && (work || A.shadow_mode <= 1u);
+    const bool gen_stays = !work && cull && !hit_walk && A.scene.lean == 0 && A.scene.nodes_lds != 0u && A.shadow_mode == 0u && RT_STAY_GEN_SHADOW != 0;
     const bool stays = gen_stays || (lean_kernel && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
     const size_t lds = stack_bytes(A.scene, lean_kernel, tb, stays);
     // Rays a wave owns at a time (k_shadow): as many as leave every SIMD its four waves eight times over, at
     // most RT_SHADOW_CHUNK (staying blocks deal runs out from a counter: RT_SHADOW_CHUNK or 64).
     uint32_t chunk = 64u;
-    if (RT_SHADOW_REFILL != 0 && !lean_kernel && A.scene.refill != 0u) {
+    if (RT_SHADOW_REFILL != 0 && !lean_kernel && !hit_walk && A.scene.refill != 0u) {
         // (eight times as many waves as the device holds at once, or the last ones run on a half-empty device)
         const uint64_t rays = (uint64_t)grid * RT_BLOCK * A.scene.n_lights;
         const uint64_t fair = rays / ((uint64_t)g_cus * 16u * (gen_stays ? 2u : 8u)) / 64u * 64u;
@@ -1298,11 +1315,15 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
     const int mode = cull ? 2 : 0;
     const bool lean = A.scene.lean != 0;
     if (variant) {
-        if (work || mode == 0) *variant = mode;
+        if (hit_walk) *variant = HITS_SH;
+        else if (work || mode == 0) *variant = mode;
         else if (A.shadow_mode == 1 || A.shadow_mode == 2) *variant = lean ? LEAN_SH : 2;
         else *variant = lean ? LEAN_SH : (gen_stays ? GEN_SH : 2);
     }
-    if (work) {
+    if (hit_walk) {
+        if (work) hipLaunchKernelGGL((k_shadow<HITS_SH, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+        else hipLaunchKernelGGL((k_shadow<HITS_SH, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+    } else if (work) {
         if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);
         else hipLaunchKernelGGL((k_shadow<0, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);
     } else if (mode == 2 && A.shadow_mode == 1) {
@@ -1357,7 +1378,8 @@ hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, cons
                                   const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist,
                                   float* out_normal, hipStream_t st) {
     const dim3 g((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), b(RT_BLOCK);
-    if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    if (cull && S.hit_walk != 0u) hipLaunchKernelGGL(k_debug_intersect<HITS_ID>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    else if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     return hipGetLastError();
 }

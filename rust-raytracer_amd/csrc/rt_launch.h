@@ -27,6 +27,7 @@
 // The "lean" kernels keep the whole stack in LDS and are only used on trees up to
 // RT_STACK_RING levels deep.
 #define RT_STACK_RING 8
+#define HITWALK_NODE_BITS 21  // the hit-list walk keeps a node index in this many bits of a stack word
 #define RT_STACK_DEEP 56   // per-lane LDS words of the culled leaf walk, after the traversal stack
 
 namespace rtamd {
@@ -66,6 +67,12 @@ struct DevScene {
     uint32_t nodes_lds;        // 1: not lean, and the node array is small enough for a copy in every staying block's LDS
     uint32_t refill;           // 1: shadow waves own a run of rays and their lanes take the next ray as they finish
                                // (trees of small leaves, where rays differ most in the number of leaves they visit)
+    // The hit-list walk (rt_traverse.h, HitWalk): hit_walk != 0 -> the scene has the tables it needs.
+    uint32_t hit_walk;
+    uint32_t all_w;            // "leaf" of ALL primitives, each once, list position = primitive index: its record's
+    uint4 all_q2, all_q3;      // three words as in `nodes` (runs in the arrays above, behind the real leaves')
+    const float4* prim_box;    // 2 per primitive: {corner, -} {fl(corner + extent), -}, src/shape.rs:37-39
+    const uint32_t* prim_entry;  // per primitive: kind << 30 | its entry in that leaf's runs (sph, cone_items, poly_rec / 4)
     float bg[3];
     float root_min[3], root_max[3];  // the root node's box
     float reach;                     // the largest coordinate, in size, of that box (and so of every node's)

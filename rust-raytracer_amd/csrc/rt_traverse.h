@@ -88,12 +88,24 @@ struct LeafBest {
         have = false; t = 0.0f; pos = 0u; prim = NO_PRIM; sphere = NO_PRIM; n = f3(0.0f, 0.0f, 0.0f);
     }
     RT_DEV bool better(float tt, uint32_t p) const { return !have || tt < t || (tt == t && p < pos); }
+    // An accepted hit of a sphere-run entry (its normal is formed later, for the one that wins) or of a cone
+    // or polygon; `p` is its position in the leaf's list.
+    RT_DEV void offer_sphere(float tt, uint32_t p, uint32_t primitive, uint32_t entry) {
+        if (better(tt, p)) {
+            have = true; t = tt; pos = p; prim = primitive; sphere = entry;
+        }
+    }
+    RT_DEV void offer_shape(float tt, uint32_t p, uint32_t primitive, F3 normal) {
+        if (better(tt, p)) {
+            have = true; t = tt; pos = p; prim = primitive; sphere = NO_PRIM; n = normal;
+        }
+    }
 };
 
 // Lanes whose quick test passed: the rest of Sphere::intersect (src/sphere.rs:55-76).
-template <bool U, class Ctr>
+template <bool U, class LB, class Ctr>
 RT_DEV void sphere_finish(const DevScene& S, uint32_t entry, float d, float c, float a, float near, uint32_t ignore,
-                          LeafBest& lb, Ctr& ctr) {
+                          LB& lb, Ctr& ctr) {
     const float b = 2.0f * d;
     const float disc = b * b - 4.0f * a * c;
     if (disc >= 0.0f) {
@@ -106,9 +118,7 @@ RT_DEV void sphere_finish(const DevScene& S, uint32_t entry, float d, float c, f
                 if constexpr (Ctr::kEnabled) {
                     if ((id.y >> 31) == 0u) ctr.sphere_hits(1);  // padding copies are not the reference's work
                 }
-                if (lb.better(t, id.y)) {
-                    lb.have = true; lb.t = t; lb.pos = id.y; lb.prim = id.x; lb.sphere = entry;
-                }
+                lb.offer_sphere(t, id.y, id.x, entry);
             }
         }
     }
@@ -123,16 +133,16 @@ RT_DEV bool sphere_quick(float cx, float cy, float cz, float rr, F3 src, F3 ray,
     return d * d >= a * c;
 }
 
-template <class Ctr>
-RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, float near, uint32_t ignore, LeafBest& lb,
+template <class LB, class Ctr>
+RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, float near, uint32_t ignore, LB& lb,
                      Ctr& ctr);
 
 // BATCH (lanes on their own, U false): eight entries per step, their loads in flight together
 // (runs are padded to a multiple of 8 entries); otherwise entry by entry, which is what the
 // counters of the reference's own work need.
-template <bool U, bool BATCH, class Ctr>
+template <bool U, bool BATCH, class LB, class Ctr>
 RT_DEV void leaf_spheres(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, float a, float near,
-                         uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+                         uint32_t ignore, LB& lb, Ctr& ctr) {
     if constexpr (!U && BATCH) {
         for (uint32_t k0 = 0; k0 < count; k0 += 8u) cluster8(S, first + k0, src, ray, a, near, ignore, lb, ctr);
     } else if constexpr (U) {
@@ -192,8 +202,8 @@ RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 n, Ctr& c
 // may use the records (un = its unit direction).  The full tests cost 5 to 10 times a record's.
 // A lane on its own (U false) tries the records eight at a time -- eight loads in flight instead
 // of one after the other, on walks that wait for memory -- and then visits the items left.
-template <bool U, class Ctr>
-RT_DEV void cone_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+template <bool U, class LB, class Ctr>
+RT_DEV void cone_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LB& lb, Ctr& ctr) {
     {
         const uint4 it = ld_u4<U>(S.cone_items, i);  // {prim, list position, cone index, -}
         // {base, base radius} {w, axis length} {u, radius difference} {v, -}, stored per entry: these
@@ -210,16 +220,14 @@ RT_DEV void cone_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near,
         F3 n;
         if (isect_cone(f3(c0.x, c0.y, c0.z), c0.w, fr, src, ray, near, t, n)) {
             ctr.cone_hits(1);
-            if (lb.better(t, it.y)) {
-                lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
-            }
+            lb.offer_shape(t, it.y, it.x, n);
         }
     }
 }
 
-template <bool U, int BND, class Ctr>
+template <bool U, int BND, class LB, class Ctr>
 RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, F3 un, bool ok, float near,
-                       uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+                       uint32_t ignore, LB& lb, Ctr& ctr) {
     if constexpr (BND != 0 && !U) {
         if (ok) {
             for (uint32_t k0 = 0; k0 < count; k0 += 8u) {
@@ -246,8 +254,8 @@ RT_DEV void leaf_cones(const DevScene& S, uint32_t first, uint32_t count, F3 src
 
 // GUARD: the test may stop before its edge loop when the plane is met outside the polygon's
 // extent (polygon_test; the exhaustive walk does not).
-template <bool U, bool GUARD, class Ctr>
-RT_DEV void polygon_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+template <bool U, bool GUARD, class LB, class Ctr>
+RT_DEV void polygon_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float near, uint32_t ignore, LB& lb, Ctr& ctr) {
     // {prim, list position, first vertex, n vertices} {plane} {extent} {first vertex}: one cache line
     const float4 r0 = ld_f4<U>(S.poly_rec, i * 4u), plane = ld_f4<U>(S.poly_rec, i * 4u + 1u),
                  rect = ld_f4<U>(S.poly_rec, i * 4u + 2u), p0 = ld_f4<U>(S.poly_rec, i * 4u + 3u);
@@ -259,15 +267,13 @@ RT_DEV void polygon_item(const DevScene& S, uint32_t i, F3 src, F3 ray, float ne
     const float4 guard = GUARD ? rect : no_guard();
     if (isect_polygon(S.vpos, S.vnrm, it.z, it.w, from4(p0), plane, guard, src, ray, near, t, n, ctr)) {
         ctr.poly_hits(1);
-        if (lb.better(t, it.y)) {
-            lb.have = true; lb.t = t; lb.pos = it.y; lb.prim = it.x; lb.sphere = NO_PRIM; lb.n = n;
-        }
+        lb.offer_shape(t, it.y, it.x, n);
     }
 }
 
-template <bool U, int BND, class Ctr>
+template <bool U, int BND, class LB, class Ctr>
 RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 src, F3 ray, F3 un, bool ok, float near,
-                          uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+                          uint32_t ignore, LB& lb, Ctr& ctr) {
     if constexpr (BND != 0 && !U) {
         if (ok) {
             for (uint32_t k0 = 0; k0 < count; k0 += 8u) {
@@ -395,8 +401,8 @@ RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 n, Ctr& c
 
 // The 8 spheres of entries e0 .. e0+7.  Padding entries are copies of real entries with a
 // later list position: whatever a copy hits, its original hits at the same distance and wins.
-template <class Ctr>
-RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, float near, uint32_t ignore, LeafBest& lb,
+template <class LB, class Ctr>
+RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, float near, uint32_t ignore, LB& lb,
                      Ctr& ctr) {
     float4 s[8];
 #pragma unroll
@@ -427,13 +433,13 @@ RT_DEV void cluster8(const DevScene& S, uint32_t e0, F3 src, F3 ray, float a, fl
 }
 
 // The 8 polygons / cylinders of items i0 .. i0+7 (padding copies skipped), each behind its own record.
-template <bool BEHIND, class Ctr>
-RT_DEV void polygons8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, float near, uint32_t ignore, LeafBest& lb,
+template <bool BEHIND, class LB, class Ctr>
+RT_DEV void polygons8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, float near, uint32_t ignore, LB& lb,
                       Ctr& ctr) {
     leaf_polygons<false, BEHIND ? 2 : 1>(S, i0, 8u, src, ray, un, true, near, ignore, lb, ctr);
 }
-template <bool BEHIND, class Ctr>
-RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, float near, uint32_t ignore, LeafBest& lb,
+template <bool BEHIND, class LB, class Ctr>
+RT_DEV void cylinders8(const DevScene& S, uint32_t i0, F3 src, F3 ray, F3 un, float near, uint32_t ignore, LB& lb,
                        Ctr& ctr) {
     leaf_cones<false, BEHIND ? 2 : 1>(S, i0, 8u, src, ray, un, true, near, ignore, lb, ctr);
 }
@@ -541,9 +547,9 @@ struct NoOccluder {
 // polygon_bound / cylinder_bound (leaf_cluster.cpp) derives for it, and the records and their
 // test are the same as for spheres (KIND 0).
 // LREC: the bounding records are read from `lrec`, the block's LDS copy of S.bnd (lean kernels).
-template <int KIND, bool BEHIND, bool LREC, class Ctr, class Occ, class St>
+template <int KIND, bool BEHIND, bool LREC, class LB, class Ctr, class Occ, class St>
 RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, F3 un, float a,
-                          float near, uint32_t ignore, LeafBest& lb, Ctr& ctr, uint32_t* lq, uint32_t stride, Occ& occ,
+                          float near, uint32_t ignore, LB& lb, Ctr& ctr, uint32_t* lq, uint32_t stride, Occ& occ,
                           const St& st, lds_cf4_ptr lrec) {
     const float4 hf = LREC ? ld_lds(lrec, header) : S.bnd[header];
     ctr.bound_tests(1);
@@ -624,9 +630,9 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
     drain();
 }
 
-template <bool U, int BND, bool BATCH, class Ctr>
+template <bool U, int BND, bool BATCH, class LB, class Ctr>
 RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, F3 un, bool ok_cone, bool ok_poly, float a,
-                      float near, uint32_t ignore, LeafBest& lb, Ctr& ctr) {
+                      float near, uint32_t ignore, LB& lb, Ctr& ctr) {
     if (q2.y) leaf_spheres<U, BATCH>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
     if (q2.w) leaf_cones<U, BND>(S, q2.z, q2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
     if (q3.y) leaf_polygons<U, BND>(S, q3.x, q3.y, src, ray, un, ok_poly, near, ignore, lb, ctr);
@@ -897,6 +903,225 @@ struct KdWalk {
     }
 };
 
+// ---------------------------------------------------------------------------------------
+// The hit-list walk: the same answer as KdWalk's, found in two steps.
+//
+// What a ray's walk through the partition returns depends on the primitives in two ways only: through the
+// hits the ray has with them, each a property of ray and primitive alone (Shape::intersect with the walk's
+// `near`, the ignored primitive left out, src/space_partition.rs:361-369), and through which leaves hold
+// which primitive.  A leaf's answer is the nearest of the hits of its members, the first in its list among
+// equals (:370-381); leaves none of whose members the ray hits answer "none", and so does a sub-tree made of
+// such leaves, whatever its boxes say.
+//   (A) All hits of the ray, each primitive tested once: the scene carries one more "leaf" that lists every
+// primitive (DevScene::all_*), with the same runs and bounding records as a real leaf, and step (A) walks
+// it as KdWalk::round walks a leaf, keeping every accepted hit {primitive, distance} in the lane's LDS words instead of the nearest one.
+// The partition's leaves hold most primitives several times (1.9 times on average in a scene of rings, 2.7
+// in a mesh), and a ray's walk visits leaf after leaf -- each a round of node steps, up to three record
+// hierarchies and a short list, every phase as long as its slowest lane; here a wave does one descent and
+// one drain.
+//   (B) The reference's walk (src/space_partition.rs:268-346) over the sub-trees that hold a hit primitive.
+// Which hits' primitives a child holds follows from what made the child's list: split() (:160-169) sends a
+// primitive over when fl(corner + extent) > plane on the node's axis and under when corner <= plane, so a
+// mask of "hits still with us" is carried down, split by those two comparisons on the primitives' boxes
+// (DevScene::prim_box; the host checks, scene by scene, that the leaves are what these comparisons make of
+// the boxes, or does not offer this walk).  A child without hits is not entered -- its visit would return
+// none -- and is treated as the walk treats a child whose box the ray misses; boxes are tested as ever (a
+// box CAN cut off a primitive the ray hits: the appraisal's boxes and split()'s lists disagree about a
+// primitive that ends on the plane).  At a leaf the mask is the set of its members among the hits.
+// Shadow rays whose hits all lie beyond the light skip (B): whatever the walk returns is one of the hits.
+// A ray with more hits than its LDS words hold, or one the bounding records cannot take (near < 0, huge or
+// tiny coordinates), is walked by KdWalk.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t HIT_CAP = RT_STACK_RING;  // hits a lane keeps: during (A) in the LDS words of its traversal stack
+constexpr uint32_t HW_NODE_MASK = (1u << HITWALK_NODE_BITS) - 1u;
+static_assert(HIT_CAP == 8u && HITWALK_NODE_BITS + 8 <= 29, "a stack word holds a node index, the mask of hits, a flag and an axis");
+static_assert(2u * HIT_CAP <= RT_LANE_WORDS, "the hits move to the lane words for (B)");
+
+struct HitList {
+    uint2* slot;  // hit k at slot[k * stride]: {primitive, bits of the distance}
+    uint32_t stride, n;
+    bool over;
+    RT_DEV void init(uint2* lane_base, uint32_t lane_stride) { slot = lane_base; stride = lane_stride; n = 0u; over = false; }
+    RT_DEV void put(uint32_t prim, float t) {
+        if (n < HIT_CAP) {
+            slot[n * stride] = make_uint2(prim, __float_as_uint(t));
+            ++n;
+        } else {
+            over = true;
+        }
+    }
+    // (a sphere run's padding entries are copies of real ones: bit 31 of their position)
+    RT_DEV void offer_sphere(float t, uint32_t pos, uint32_t prim, uint32_t) { if ((pos >> 31) == 0u) put(prim, t); }
+    RT_DEV void offer_shape(float t, uint32_t, uint32_t prim, F3) { put(prim, t); }
+};
+
+// unwind() for step (B): a stack word also carries the far child's mask of hits.
+template <class Ctr>
+RT_DEV bool unwind_hits(KdStack<true>& st, F3 src, F3 ray, bool& r_hit, float r_dist, uint32_t& cur, uint32_t& mask, Ctr& ctr) {
+    while (!st.empty()) {
+        const uint2 ent = st.pop();
+        const uint32_t axis = ent.x >> 30;
+        const float plane = __uint_as_float(ent.y);
+        bool take_second = !r_hit;
+        if (r_hit) {
+            const float endpoint = comp(src, axis) + comp(ray, axis) * r_dist;  // src/space_partition.rs:316, :334
+            const bool under_first = comp(src, axis) < plane;
+            take_second = under_first ? (endpoint > plane) : (endpoint < plane);
+        }
+        if (take_second) {
+            r_hit = false;
+            if ((ent.x & FAR_BOX_HIT) != 0u) {
+                ctr.node_visits(1);
+                cur = ent.x & HW_NODE_MASK;
+                mask = (ent.x >> HITWALK_NODE_BITS) & 0xffu;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+template <int CULL, class Ctr, int OCC = 0>
+RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
+                                uint2* stack, Ctr& ctr, float limit = 0.0f);
+
+// MODE: 1 / 2 as CULL's low bits.  SHADOW: only "is the walk's hit at most `limit` away" is wanted (out.dist is
+// the walk's distance when it returns true; no normal is formed).
+template <int MODE, bool SHADOW, class Ctr>
+RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out, uint2* stack,
+                             Ctr& ctr, float limit) {
+    static_assert(MODE == 1 || MODE == 2, "the hit-list walk goes by the bounding records");
+    const uint32_t stride = blockDim.x;
+    uint2* const ring = stack + threadIdx.x;
+    uint32_t* const lane_words = (uint32_t*)(stack + (uint32_t)RT_STACK_RING * stride) + threadIdx.x;
+    const float a = dot(ray, ray);  // src/sphere.rs:51
+    // (what the bounding-record tests ask of a ray, KdWalk::begin; near >= 0 for the cylinders' records and the
+    // look behind the origin)
+    const bool tame = a >= 1e-30f && a < 1e16f && dot(src, src) < 1e16f && near >= 0.0f;
+    out.dist = 0.0f; out.prim = NO_PRIM; out.n = f3(0.0f, 0.0f, 0.0f);
+    const RayInv ri = ray_inv_of(src, ray, S.reach);
+    ctr.node_visits(1);
+    const bool in_root = box_passes<false>(f3(S.root_min[0], S.root_min[1], S.root_min[2]), f3(S.root_max[0], S.root_max[1], S.root_max[2]),
+                                           src, ray, near, ri);  // src/space_partition.rs:276-279
+    HitList hl;
+    hl.init(ring, stride);
+    if (tame && in_root) {  // ---- (A)  the walk of a leaf (KdWalk::round), of the leaf that lists every primitive
+        constexpr bool BEHIND = MODE == 2;
+        const F3 un = unit_ray(ray, a);
+        NoOccluder occ;
+        const lds_cf4_ptr no_lrec = (lds_cf4_ptr) nullptr;
+        uint4 q2 = S.all_q2, q3 = S.all_q3;  // (the same for every lane: scalar registers)
+        if (q2.y >= CULL_MIN_SPHERES) {  // spheres, through their bounding records
+            leaf_run_lane<0, BEHIND, false>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+            q2.y = 0u;
+        }
+        if (q3.w != 0xffffffffu) {  // polygons
+            leaf_run_lane<1, BEHIND, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+            q3.y = 0u;
+        }
+        if (S.all_w != 0xffffffffu) {  // cylinders (the cone items before q2.z)
+            const uint32_t cyl_n = __float_as_uint(S.bnd[S.all_w].w) >> 3;
+            leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+        }
+        // cones proper, which no record bounds: every lane tests every one (entries by scalar loads when they are many)
+        if (q2.w >= BIG_LEAF) {
+            leaf_cones<true, MODE>(S, q2.z, q2.w, src, ray, un, true, near, ignore, hl, ctr);
+            q2.w = 0u;
+        }
+        leaf_runs<false, MODE, true>(S, q2, q3, src, ray, un, true, true, a, near, ignore, hl, ctr);  // what is left: short runs
+    }
+    bool r_hit = false;
+    if (!tame || hl.over) {  // (rare)
+        if (in_root) r_hit = kd_traverse_closest<MODE, Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        return r_hit;
+    }
+    uint32_t mask = (1u << hl.n) - 1u;
+    if constexpr (SHADOW) {
+        bool any = false;
+        for (uint32_t k = 0; k < hl.n; ++k) any = any || __uint_as_float(ring[k * stride].y) <= limit;
+        if (!any) mask = 0u;
+    }
+    if (mask == 0u) return false;
+
+    // ---- (B)  the hits move to the lane words: the traversal stack takes its LDS words back
+    for (uint32_t k = 0; k < hl.n; ++k) {
+        const uint2 e = ring[k * stride];
+        lane_words[(2u * k) * stride] = e.x;
+        lane_words[(2u * k + 1u) * stride] = e.y;
+    }
+    KdDeep<true> deep;
+    KdStack<true> st;
+    st.init(ring, stride, deep.e);
+    uint32_t cur = 0u;
+    float r_dist = 0.0f;
+    uint32_t r_prim = NO_PRIM;
+    for (bool done = false; !done;) {
+        const uint4 n0 = S.nodes[cur * 4 + 0], n1 = S.nodes[cur * 4 + 1], n2 = S.nodes[cur * 4 + 2], n3 = S.nodes[cur * 4 + 3];
+        const uint32_t axis = n0.y;
+        if (axis == AXIS_LEAF) {
+            // the leaf's members among the hits: the nearest, the first in the list among equals (a leaf's list is
+            // in the scene's order, so the smaller primitive index)
+            r_hit = false;
+            for (uint32_t m = mask; m != 0u; m &= m - 1u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(m);
+                const uint32_t prim = lane_words[(2u * k) * stride];
+                const float t = __uint_as_float(lane_words[(2u * k + 1u) * stride]);
+                if (!r_hit || t < r_dist || (t == r_dist && prim < r_prim)) {
+                    r_hit = true; r_dist = t; r_prim = prim;
+                }
+            }
+            if (!unwind_hits(st, src, ray, r_hit, r_dist, cur, mask, ctr)) done = true;
+        } else {
+            ctr.interior_steps(1);
+            const float plane = __uint_as_float(n0.x);
+            const bool under_first = comp(src, axis) < plane;  // :303
+            uint32_t m_under = 0u, m_over = 0u;
+            for (uint32_t m = mask; m != 0u; m &= m - 1u) {  // split(), :160-169
+                const uint32_t k = (uint32_t)__builtin_ctz(m);
+                const uint32_t prim = lane_words[(2u * k) * stride];
+                const float4 lo = S.prim_box[prim * 2u], hi = S.prim_box[prim * 2u + 1u];
+                if (comp(f3(hi.x, hi.y, hi.z), axis) > plane) m_over |= 1u << k;
+                if (comp(f3(lo.x, lo.y, lo.z), axis) <= plane) m_under |= 1u << k;
+            }
+            const F3 umin = f3(__uint_as_float(n1.x), __uint_as_float(n1.y), __uint_as_float(n1.z));
+            const F3 umax = f3(__uint_as_float(n1.w), __uint_as_float(n2.x), __uint_as_float(n2.y));
+            const F3 omin = f3(__uint_as_float(n2.z), __uint_as_float(n2.w), __uint_as_float(n3.x));
+            const F3 omax = f3(__uint_as_float(n3.y), __uint_as_float(n3.z), __uint_as_float(n3.w));
+            const bool hit_u = m_under != 0u && box_passes<false>(umin, umax, src, ray, near, ri);
+            const bool hit_o = m_over != 0u && box_passes<false>(omin, omax, src, ray, near, ri);
+            const bool hit_first = under_first ? hit_u : hit_o, hit_second = under_first ? hit_o : hit_u;
+            const uint32_t m_first = under_first ? m_under : m_over, m_second = under_first ? m_over : m_under;
+            st.push(make_uint2((under_first ? n0.w : n0.z) | (m_second << HITWALK_NODE_BITS) | (hit_second ? FAR_BOX_HIT : 0u) | (axis << 30), n0.x));
+            if (hit_first) {
+                ctr.node_visits(1);
+                cur = under_first ? n0.z : n0.w;
+                mask = m_first;
+            } else {
+                r_hit = false;
+                if (!unwind_hits(st, src, ray, r_hit, r_dist, cur, mask, ctr)) done = true;
+            }
+        }
+    }
+    if (!r_hit) return false;
+    out.dist = r_dist;
+    out.prim = r_prim;
+    if constexpr (!SHADOW) {
+        // the normal of the one hit that is the answer: its primitive's test once more (the same operands, the same bits)
+        const uint32_t code = S.prim_entry[r_prim], i = code & 0x3fffffffu;
+        if ((code >> 30) == 0u) {
+            const float4 s = S.sph[i];
+            out.n = sphere_normal(f3(s.x, s.y, s.z), src, ray, r_dist);
+        } else {
+            LeafBest lb;
+            lb.init();
+            if ((code >> 30) == 1u) cone_item<false>(S, i, src, ray, near, NO_PRIM, lb, ctr);
+            else polygon_item<false, true>(S, i, src, ray, near, NO_PRIM, lb, ctr);
+            out.n = lb.n;
+        }
+    }
+    return true;
+}
+
 // CULL: 0 = every entry of every visited leaf, 1 = big runs skip groups the ray's line misses,
 // 2 = also groups behind the ray's origin (worth its cost for rays that start inside the
 // scene); + 4 = the scene has neither cones nor polygon runs with bounding records, and the
@@ -907,15 +1132,19 @@ struct KdWalk {
 // as soon as the answer "a hit at most that far" is certain (1, Occluder) or as soon as any such
 // hit is found (2, not the reference's answer in every case); out.dist is then some distance <=
 // limit, not the nearest.
-template <int CULL, class Ctr, int OCC = 0>
+template <int CULL, class Ctr, int OCC>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
-                                uint2* stack, Ctr& ctr, float limit = 0.0f) {
-    KdDeep<(CULL & 4) == 0> deep;
-    KdWalk<CULL, Ctr, OCC> w(S, stack, ctr, deep);
-    w.begin(src, ray, near, ignore, limit);
-    while (!w.done) w.round();
-    out = w.r;
-    return w.r_hit;
+                                uint2* stack, Ctr& ctr, float limit) {
+    if constexpr ((CULL & 64) != 0) {  // (+ 64: the hit-list walk)
+        return kd_traverse_hits<CULL & 3, false>(S, src, ray, near, ignore, out, stack, ctr, limit);
+    } else {
+        KdDeep<(CULL & 4) == 0> deep;
+        KdWalk<CULL, Ctr, OCC> w(S, stack, ctr, deep);
+        w.begin(src, ray, near, ignore, limit);
+        while (!w.done) w.round();
+        out = w.r;
+        return w.r_hit;
+    }
 }
 
 }  // namespace RT_NS
