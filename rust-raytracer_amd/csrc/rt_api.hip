@@ -944,7 +944,9 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // frame 1.40 -> 1.10 ms) at the price of blocks that stay while their rays dwindle; a frame begun with two
     // or more others in flight, whose gaps those fill anyway, keeps one launch per level (4.63 ms per frame
     // against 4.72 with four in flight).
-    const bool fused = !work && cull && ctx->fuse_deep && !(f.one_stream && !serial) &&
+    // (The per-level launches of the hit-list walk are one-wave blocks that take twice the time of its one
+    // launch for all levels, rings 4: 15.3 against 8.0 ms: those scenes keep the one launch whatever is in flight.)
+    const bool fused = !work && cull && ctx->fuse_deep && !(f.one_stream && !serial && scene->dev.hit_walk == 0u) &&
                        (fast ? rt_fast::can_fuse(A, last_level) : rt_exact::can_fuse(A, last_level));
     const int hm = fused ? 1 : 0;  // which set of level sizes applies
     const bool hinted = ctx->hint_valid[hm] && ctx->hint_scene == scene->serial && ctx->hint_slots == n_slots && ctx->hint_depth == opt->max_depth;

@@ -684,6 +684,12 @@ __device__ unsigned long long g_phase[8];
 #define RT_PHASE(k) do {} while (0)
 #define RT_PHASE_END() do {} while (0)
 #endif
+#ifdef RT_X_PHASE  // (the same experiment's counts for the hit-list walk: rays, rays walked leaf by leaf, hits, rays in step (B), its interior steps, its leaves)
+__device__ unsigned long long g_hitstat[8];
+#define RT_HITSTAT(k, v) atomicAdd(&g_hitstat[k], (unsigned long long)(v))
+#else
+#define RT_HITSTAT(k, v) do {} while (0)
+#endif
 
 // The staying blocks' copies of scene data in LDS, made by all threads of a block when it starts (behind
 // the traversal stack and the lane words; a barrier follows): the bounding records (lean kernels), or the
@@ -1005,6 +1011,8 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
                                            src, ray, near, ri);  // src/space_partition.rs:276-279
     HitList hl;
     hl.init(ring, stride);
+    RT_PHASE_T0();
+    RT_HITSTAT(0, 1u);
     if (tame && in_root) {  // ---- (A)  the walk of a leaf (KdWalk::round), of the leaf that lists every primitive
         constexpr bool BEHIND = MODE == 2;
         const F3 un = unit_ray(ray, a);
@@ -1015,23 +1023,29 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
             leaf_run_lane<0, BEHIND, false>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
             q2.y = 0u;
         }
+        RT_PHASE(1);
         if (q3.w != 0xffffffffu) {  // polygons
             leaf_run_lane<1, BEHIND, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
             q3.y = 0u;
         }
+        RT_PHASE(2);
         if (S.all_w != 0xffffffffu) {  // cylinders (the cone items before q2.z)
             const uint32_t cyl_n = __float_as_uint(S.bnd[S.all_w].w) >> 3;
             leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
         }
+        RT_PHASE(3);
         // cones proper, which no record bounds: every lane tests every one (entries by scalar loads when they are many)
         if (q2.w >= BIG_LEAF) {
             leaf_cones<true, MODE>(S, q2.z, q2.w, src, ray, un, true, near, ignore, hl, ctr);
             q2.w = 0u;
         }
         leaf_runs<false, MODE, true>(S, q2, q3, src, ray, un, true, true, a, near, ignore, hl, ctr);  // what is left: short runs
+        RT_PHASE(4);
     }
     bool r_hit = false;
+    RT_HITSTAT(2, hl.n);
     if (!tame || hl.over) {  // (rare)
+        RT_HITSTAT(1, 1u);
         if (in_root) r_hit = kd_traverse_closest<MODE, Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
         return r_hit;
     }
@@ -1041,7 +1055,11 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
         for (uint32_t k = 0; k < hl.n; ++k) any = any || __uint_as_float(ring[k * stride].y) <= limit;
         if (!any) mask = 0u;
     }
-    if (mask == 0u) return false;
+    if (mask == 0u) {
+        RT_PHASE_END();
+        return false;
+    }
+    RT_HITSTAT(3, 1u);
 
     // ---- (B)  the hits move to the lane words: the traversal stack takes its LDS words back
     for (uint32_t k = 0; k < hl.n; ++k) {
@@ -1070,9 +1088,11 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
                     r_hit = true; r_dist = t; r_prim = prim;
                 }
             }
+            RT_HITSTAT(5, 1u);
             if (!unwind_hits(st, src, ray, r_hit, r_dist, cur, mask, ctr)) done = true;
         } else {
             ctr.interior_steps(1);
+            RT_HITSTAT(4, 1u);
             const float plane = __uint_as_float(n0.x);
             const bool under_first = comp(src, axis) < plane;  // :303
             uint32_t m_under = 0u, m_over = 0u;
@@ -1102,7 +1122,11 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
             }
         }
     }
-    if (!r_hit) return false;
+    RT_PHASE(0);
+    if (!r_hit) {
+        RT_PHASE_END();
+        return false;
+    }
     out.dist = r_dist;
     out.prim = r_prim;
     if constexpr (!SHADOW) {
@@ -1119,6 +1143,8 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
             out.n = lb.n;
         }
     }
+    RT_PHASE(5);
+    RT_PHASE_END();
     return true;
 }
 
