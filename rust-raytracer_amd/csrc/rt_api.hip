@@ -641,7 +641,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         for (size_t i = p_from; i < poly_items.size(); ++i)
             if ((poly_items[i].y >> 31) == 0u) prim_entry[poly_items[i].x] = (uint32_t)i | (2u << 30);
         for (uint32_t e : prim_entry)
-            if (e == 0xffffffffu || (e & 0x3fffffffu) >= (1u << 29)) hit_walk = false;
+            if (e == 0xffffffffu || (e & 0x3fffffffu) >= (1u << 26)) hit_walk = false;  // (a queued test names its item in 26 bits)
     }
 
     std::vector<float4> cones, vpos, vnrm, surfaces, lights;

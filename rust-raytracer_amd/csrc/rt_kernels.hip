@@ -417,10 +417,10 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
 constexpr uint32_t DEEP_MAX_LEVEL = 16u;      // deepest max_depth this kernel serves (per-wave ranges below)
 // Node indices a block's stack holds, and ranges a wave can keep (one per level and a few).  The blocks that
 // carry a copy of the node array (CULL + 16: 1024 threads, 152 KiB of stacks, lane words and nodes) have
-// room for less.
+// room for less, and so have those of the hit-list walk (CULL + 64: a queue of tests per wave).
 template <int CULL> struct DeepRoom {
-    static constexpr uint32_t STACK = (CULL & 16) != 0 ? 1024u : 2048u;
-    static constexpr uint32_t RANGES = (CULL & 16) != 0 ? DEEP_MAX_LEVEL + 6u : 2u * DEEP_MAX_LEVEL + 8u;
+    static constexpr uint32_t STACK = (CULL & (16 | 64)) != 0 ? 1024u : 2048u;
+    static constexpr uint32_t RANGES = (CULL & (16 | 64)) != 0 ? DEEP_MAX_LEVEL + 6u : 2u * DEEP_MAX_LEVEL + 8u;
 };
 constexpr uint32_t DEEP_KEEP = 48u;           // offspring of at least this many rays stays with its wave
 struct DeepCtl {
@@ -1136,10 +1136,11 @@ static uint32_t g_deep_block[4] = {512, 512, 1024, 512};  // the same for k_deep
 // The same for the staying blocks of scenes that are not lean, one block per CU: [0] k_intersect level 0,
 // [1] deeper levels, [2] k_shadow (mode 0); [0] unused.
 static uint32_t g_gen_block[3] = {1024, 1024, 1024};
-static size_t stack_bytes(const DevScene& S, bool lean_kernel, uint32_t block, bool stays) {
+static size_t stack_bytes(const DevScene& S, bool lean_kernel, uint32_t block, bool stays, bool hit_walk = false) {
     const size_t entries = lean_kernel ? S.stack_depth : RT_STACK_RING;
-    // (+ a staying block's copy of the bounding records, or of the nodes)
-    const size_t copy = !stays ? 0 : (lean_kernel ? (size_t)S.bnd_records * sizeof(float4) : (size_t)S.n_nodes * 64u);
+    // (+ a staying block's copy of the bounding records, or of the nodes; or the waves' queues of the hit-list walk)
+    const size_t copy = hit_walk ? (size_t)(block / 64u) * RT_WAVE_QUEUE * sizeof(uint32_t)
+                                 : (!stays ? 0 : (lean_kernel ? (size_t)S.bnd_records * sizeof(float4) : (size_t)S.n_nodes * 64u));
     return entries * block * sizeof(uint2) + (size_t)RT_LANE_WORDS * block * sizeof(uint32_t) + copy;
 }
 
@@ -1244,7 +1245,7 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
     const bool stays = gen_stays || (!work && cull && lean && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
     const dim3 g(blocks_of(grid, tb, stays, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU)), b(tb);
-    const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays);
+    const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays, hit_walk);
     if (variant) {
         if (level == 0) *variant = !cull ? 0 : (hit_walk ? HITS_I0 : (!work && lean ? LEAN_I0 : 1));
         else *variant = !cull ? 0 : (hit_walk ? HITS_ID : (work ? 2 : (lean ? LEAN_ID : (gen_stays ? GEN_ID : 2))));
@@ -1293,7 +1294,7 @@ hipError_t launch_deep(const FrameArgs& A, uint32_t grid, uint32_t per_cu, hipSt
     const uint32_t tb = g_deep_block[lean ? 0 : (hit_walk ? 3 : (lds_nodes ? 2 : 1))];
     const uint32_t most = lds_nodes ? 1u : RT_LEAN_BLOCKS_PER_CU;
     const dim3 g(blocks_of(grid, tb, true, per_cu != 0u && per_cu < most ? per_cu : most)), b(tb);
-    const size_t lds = stack_bytes(A.scene, lean, tb, lean || lds_nodes);
+    const size_t lds = stack_bytes(A.scene, lean, tb, lean || lds_nodes, hit_walk);
     if (variant) *variant = (lean ? LEAN_ID : (hit_walk ? HITS_ID : (lds_nodes ? GEN_ID : 2))) + 32;  // (+ 32: all deeper levels in one launch)
     if (lean) hipLaunchKernelGGL((k_deep<LEAN_ID, NoCounters>), g, b, lds, st, A);
     else if (hit_walk) hipLaunchKernelGGL((k_deep<HITS_ID, NoCounters>), g, b, lds, st, A);
@@ -1311,7 +1312,7 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
     const bool gen_stays = !work && cull && !hit_walk && A.scene.lean == 0 && A.scene.nodes_lds != 0u && A.shadow_mode == 0u && RT_STAY_GEN_SHADOW != 0;
     const bool stays = gen_stays || (lean_kernel && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
-    const size_t lds = stack_bytes(A.scene, lean_kernel, tb, stays);
+    const size_t lds = stack_bytes(A.scene, lean_kernel, tb, stays, hit_walk);
     // Rays a wave owns at a time (k_shadow): as many as leave every SIMD its four waves eight times over, at
     // most RT_SHADOW_CHUNK (staying blocks deal runs out from a counter: RT_SHADOW_CHUNK or 64).
     uint32_t chunk = 64u;
@@ -1392,7 +1393,7 @@ hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, cons
                                   const float* near, const uint32_t* ignore, uint32_t* out_prim, float* out_dist,
                                   float* out_normal, hipStream_t st) {
     const dim3 g((uint32_t)((n + RT_BLOCK - 1) / RT_BLOCK)), b(RT_BLOCK);
-    if (cull && S.hit_walk != 0u) hipLaunchKernelGGL(k_debug_intersect<HITS_ID>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
+    if (cull && S.hit_walk != 0u) hipLaunchKernelGGL(k_debug_intersect<HITS_ID>, g, b, stack_bytes(S, false, RT_BLOCK, false, true), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     else if (cull) hipLaunchKernelGGL(k_debug_intersect<2>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     else hipLaunchKernelGGL(k_debug_intersect<0>, g, b, stack_bytes(S, false, RT_BLOCK, false), st, S, n, src, ray, near, ignore, out_prim, out_dist, out_normal);
     return hipGetLastError();

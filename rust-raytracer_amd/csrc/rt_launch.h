@@ -27,6 +27,9 @@
 // The "lean" kernels keep the whole stack in LDS and are only used on trees up to
 // RT_STACK_RING levels deep.
 #define RT_STACK_RING 8
+#ifndef RT_WAVE_QUEUE
+#define RT_WAVE_QUEUE 256     // the hit-list walk: LDS words per wave for its queue of cone and polygon tests
+#endif
 #define HITWALK_NODE_BITS 21  // the hit-list walk keeps a node index in this many bits of a stack word
 #define RT_STACK_DEEP 56   // per-lane LDS words of the culled leaf walk, after the traversal stack
 

@@ -78,6 +78,8 @@ struct Hit {
 
 // Nearest hit of one leaf visit.
 struct LeafBest {
+    static constexpr bool kQueued = false;        // cone and polygon tests run where their candidates are found
+    static constexpr uint32_t kLaneQueue = RT_LANE_WORDS - 4;  // level-1 groups a lane's walk of a run queues before it drains them (LANE_QUEUE)
     bool have;
     float t;
     uint32_t pos;     // position in the leaf's primitive list (tie-break)
@@ -573,7 +575,16 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             }
             const uint32_t k = (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
-            if constexpr (KIND == 1) polygons8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
+            if constexpr (KIND != 0 && LB::kQueued) {
+                // the eight items' own records here; the tests of those that pass, later, by whichever lanes are free
+                const uint32_t i0 = first + (g * 8u + k) * 8u;
+                uint32_t pm = expand8<BEHIND>((KIND == 1 ? S.poly_bound : S.cone_bound) + i0, 8u, src, un, ctr);
+                while (pm != 0u) {
+                    const uint32_t kk = (uint32_t)__builtin_ctz(pm);
+                    pm &= pm - 1u;
+                    lb.template push_item<KIND>(S, i0 + kk, src, ray, near, ignore, ctr);
+                }
+            } else if constexpr (KIND == 1) polygons8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
             else if constexpr (KIND == 2) cylinders8<BEHIND>(S, first + (g * 8u + k) * 8u, src, ray, un, near, ignore, lb, ctr);
             else cluster8(S, first + (g * 8u + k) * 8u, src, ray, a, near, ignore, lb, ctr);
             if constexpr (Occ::kOn) {
@@ -598,7 +609,7 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
                     ctr.bound_passes((uint32_t)__builtin_popcount(m));
                     lq[(LANE_STACK + qn) * stride] = (g << 8) | m;
                     ++qn;
-                    if (qn == LANE_QUEUE) {
+                    if (qn == LB::kLaneQueue) {
                         drain();
                         if constexpr (Occ::kOn) {
                             if (occ.hit) return;
@@ -938,27 +949,110 @@ struct KdWalk {
 // A ray with more hits than its LDS words hold, or one the bounding records cannot take (near < 0, huge or
 // tiny coordinates), is walked by KdWalk.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t HIT_CAP = RT_STACK_RING;  // hits a lane keeps: during (A) in the LDS words of its traversal stack
+constexpr uint32_t HIT_CAP = RT_STACK_RING - 1;  // hits a lane keeps: during (A) in the LDS words of its traversal stack
 constexpr uint32_t HW_NODE_MASK = (1u << HITWALK_NODE_BITS) - 1u;
-static_assert(HIT_CAP == 8u && HITWALK_NODE_BITS + 8 <= 29, "a stack word holds a node index, the mask of hits, a flag and an axis");
+static_assert(HIT_CAP <= 8u && HITWALK_NODE_BITS + 8 <= 29, "a stack word holds a node index, the mask of hits, a flag and an axis");
 static_assert(2u * HIT_CAP <= RT_LANE_WORDS, "the hits move to the lane words for (B)");
+// The wave's queue of cone and polygon tests.  A lane's walk of a run finds its candidates a few at a time, and
+// few lanes find one at the same moment: tested on the spot, a cone test (a few hundred instructions) ran with a
+// quarter of the lanes.  So a candidate goes to a queue of the wave, {owning lane, item}, in LDS words of its own
+// behind the block's lane words, and when the lanes have come together again after the run, they take the queue 64 items at a time, each lane one, with the OWNER's ray
+// (fetched from the owner's registers), and hand a hit to the owner's list.  A candidate the queue has no room for
+// is tested on the spot.
+#ifndef RT_WQ_DIRECT
+#define RT_WQ_DIRECT 32u  // lanes with a candidate at the same moment from which it is tested on the spot
+#endif
+constexpr uint32_t WQ_CAP = RT_WAVE_QUEUE;  // items per wave
+
+RT_DEV uint32_t lane_index() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 struct HitList {
-    uint2* slot;  // hit k at slot[k * stride]: {primitive, bits of the distance}
-    uint32_t stride, n;
-    bool over;
-    RT_DEV void init(uint2* lane_base, uint32_t lane_stride) { slot = lane_base; stride = lane_stride; n = 0u; over = false; }
-    RT_DEV void put(uint32_t prim, float t) {
-        if (n < HIT_CAP) {
-            slot[n * stride] = make_uint2(prim, __float_as_uint(t));
-            ++n;
-        } else {
-            over = true;
-        }
+    static constexpr bool kQueued = true;
+    static constexpr uint32_t kLaneQueue = RT_LANE_WORDS - 4;
+    // hit k of lane j of this wave at wave0[k * stride + j]: {primitive, bits of the distance}; entry HIT_CAP: {hits the
+    // lane has (more than HIT_CAP: some were dropped), lane 0's: items in the wave's queue}
+    uint2* wave0;
+    uint32_t* wq;  // the wave's queue
+    uint32_t stride, lane;
+    RT_DEV void init(uint2* lane_ring, uint32_t* wave_queue, uint32_t lane_stride) {
+        lane = lane_index();
+        wave0 = lane_ring - lane;
+        wq = wave_queue;
+        stride = lane_stride;
+        wave0[HIT_CAP * stride + lane] = make_uint2(0u, 0u);
+        if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) *queued() = 0u;  // (lane 0 of the wave may have no ray)
+        __builtin_amdgcn_wave_barrier();
+    }
+    RT_DEV uint32_t* count_of(uint32_t j) const { return (uint32_t*)(wave0 + HIT_CAP * stride + j); }
+    RT_DEV uint32_t* queued() const { return (uint32_t*)(wave0 + HIT_CAP * stride) + 1; }
+    RT_DEV uint32_t count() const { return *count_of(lane); }
+    RT_DEV uint2 hit(uint32_t k) const { return wave0[k * stride + lane]; }
+    RT_DEV void put(uint32_t prim, float t) {  // this lane's own find
+        uint32_t* c = count_of(lane);
+        const uint32_t n = *c;
+        if (n < HIT_CAP) wave0[n * stride + lane] = make_uint2(prim, __float_as_uint(t));
+        *c = n + 1u;
+    }
+    RT_DEV void deliver(uint32_t owner, uint32_t prim, float t) {  // (several lanes may find for one owner at once)
+        const uint32_t n = atomicAdd(count_of(owner), 1u);
+        if (n < HIT_CAP) wave0[n * stride + owner] = make_uint2(prim, __float_as_uint(t));
     }
     // (a sphere run's padding entries are copies of real ones: bit 31 of their position)
     RT_DEV void offer_sphere(float t, uint32_t pos, uint32_t prim, uint32_t) { if ((pos >> 31) == 0u) put(prim, t); }
     RT_DEV void offer_shape(float t, uint32_t, uint32_t prim, F3) { put(prim, t); }
+
+    // Candidate `item` (KIND 1: entry of poly_rec, 2: of cone_items) of this lane's ray: to the wave's queue; the
+    // lanes that are here together ask for room together.
+    template <int KIND, class Ctr>
+    RT_DEV void push_item(const DevScene& S, uint32_t item, F3 src, F3 ray, float near, uint32_t ignore, Ctr& ctr) {
+        const uint64_t here = __ballot(true);
+        const uint32_t n_here = (uint32_t)__popcll(here);
+        uint32_t base = WQ_CAP;
+        // (enough lanes with a candidate right now: the test on the spot runs well filled, and costs no queueing)
+        if (n_here < RT_WQ_DIRECT && lane == (uint32_t)__builtin_ctzll(here)) base = atomicAdd(queued(), n_here);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+        if (at < WQ_CAP) {
+            wq[at] = (lane << 26) | item;
+        } else {  // no room: on the spot
+            if constexpr (KIND == 1) polygon_item<false, true>(S, item, src, ray, near, ignore, *this, ctr);
+            else cone_item<false>(S, item, src, ray, near, ignore, *this, ctr);
+        }
+    }
+    // The queued tests, by all lanes that are here (every owner is among them: they walked the run together).
+    template <int KIND, class Ctr>
+    RT_DEV void flush(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Ctr& ctr) {
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t here = __ballot(true);
+        const uint32_t n_here = (uint32_t)__popcll(here);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+        uint32_t total = __builtin_amdgcn_readfirstlane(*queued());
+        total = total < WQ_CAP ? total : WQ_CAP;
+        struct ToOwner {  // what the item tests hand their hit to
+            HitList& list;
+            uint32_t owner;
+            RT_DEV void offer_shape(float t, uint32_t, uint32_t prim, F3) { list.deliver(owner, prim, t); }
+        };
+        for (uint32_t first = 0u; first < total; first += n_here) {
+            const uint32_t at = first + rank;
+            const bool mine = at < total;
+            const uint32_t e = wq[mine ? at : 0u];
+            const int owner = (int)(e >> 26);
+            // the owner's ray, from its registers
+            const F3 o_src = f3(__shfl(src.x, owner, 64), __shfl(src.y, owner, 64), __shfl(src.z, owner, 64));
+            const F3 o_ray = f3(__shfl(ray.x, owner, 64), __shfl(ray.y, owner, 64), __shfl(ray.z, owner, 64));
+            const float o_near = __shfl(near, owner, 64);
+            const uint32_t o_ignore = (uint32_t)__shfl((int)ignore, owner, 64);
+            if (mine) {
+                ToOwner to{*this, (uint32_t)owner};
+                if constexpr (KIND == 1) polygon_item<false, true>(S, e & 0x3ffffffu, o_src, o_ray, o_near, o_ignore, to, ctr);
+                else cone_item<false>(S, e & 0x3ffffffu, o_src, o_ray, o_near, o_ignore, to, ctr);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (rank == 0u) *queued() = 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
 };
 
 // unwind() for step (B): a stack word also carries the far child's mask of hits.
@@ -1010,7 +1104,8 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     const bool in_root = box_passes<false>(f3(S.root_min[0], S.root_min[1], S.root_min[2]), f3(S.root_max[0], S.root_max[1], S.root_max[2]),
                                            src, ray, near, ri);  // src/space_partition.rs:276-279
     HitList hl;
-    hl.init(ring, stride);
+    // (the waves' queues lie behind the block's lane words)
+    hl.init(ring, (uint32_t*)(stack + (uint32_t)RT_STACK_RING * stride) + (uint32_t)RT_LANE_WORDS * stride + (threadIdx.x >> 6) * WQ_CAP, stride);
     RT_PHASE_T0();
     RT_HITSTAT(0, 1u);
     if (tame && in_root) {  // ---- (A)  the walk of a leaf (KdWalk::round), of the leaf that lists every primitive
@@ -1026,12 +1121,14 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
         RT_PHASE(1);
         if (q3.w != 0xffffffffu) {  // polygons
             leaf_run_lane<1, BEHIND, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+            hl.template flush<1>(S, src, ray, near, ignore, ctr);
             q3.y = 0u;
         }
         RT_PHASE(2);
         if (S.all_w != 0xffffffffu) {  // cylinders (the cone items before q2.z)
             const uint32_t cyl_n = __float_as_uint(S.bnd[S.all_w].w) >> 3;
             leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+            hl.template flush<2>(S, src, ray, near, ignore, ctr);
         }
         RT_PHASE(3);
         // cones proper, which no record bounds: every lane tests every one (entries by scalar loads when they are many)
@@ -1043,16 +1140,17 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
         RT_PHASE(4);
     }
     bool r_hit = false;
-    RT_HITSTAT(2, hl.n);
-    if (!tame || hl.over) {  // (rare)
+    const uint32_t n_hits = (tame && in_root) ? hl.count() : 0u;
+    RT_HITSTAT(2, n_hits);
+    if (!tame || n_hits > HIT_CAP) {  // (rare)
         RT_HITSTAT(1, 1u);
         if (in_root) r_hit = kd_traverse_closest<MODE, Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
         return r_hit;
     }
-    uint32_t mask = (1u << hl.n) - 1u;
+    uint32_t mask = (1u << n_hits) - 1u;
     if constexpr (SHADOW) {
         bool any = false;
-        for (uint32_t k = 0; k < hl.n; ++k) any = any || __uint_as_float(ring[k * stride].y) <= limit;
+        for (uint32_t k = 0; k < n_hits; ++k) any = any || __uint_as_float(ring[k * stride].y) <= limit;
         if (!any) mask = 0u;
     }
     if (mask == 0u) {
@@ -1062,7 +1160,7 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     RT_HITSTAT(3, 1u);
 
     // ---- (B)  the hits move to the lane words: the traversal stack takes its LDS words back
-    for (uint32_t k = 0; k < hl.n; ++k) {
+    for (uint32_t k = 0; k < n_hits; ++k) {
         const uint2 e = ring[k * stride];
         lane_words[(2u * k) * stride] = e.x;
         lane_words[(2u * k + 1u) * stride] = e.y;
