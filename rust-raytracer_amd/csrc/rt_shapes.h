@@ -484,20 +484,35 @@ RT_DEV bool isect_polygon(const float4* __restrict__ vpos, const float4* __restr
     t_out = h.t; n_out = h.n;
     return h.ok;
 }
+// The test up to its edge loop (src/polygon.rs:61-100, then the guard): the plane's distance and the point there
+// in the edge loop's two coordinates, or false.  It is also run on its own, to sort out the candidates that end
+// here (most do) before the loop is run for the rest, and must then decide as it does inside the test: in both
+// builds its operations are the reference's, one by one (no contraction).
+RT_DEV bool polygon_front(F3 v0, float4 plane, float4 guard, F3 src, F3 ray, float near, float& plane_dist, float& ip_minor,
+                          float& ip_major) {
+#pragma clang fp contract(off)
+    // (written out: the pragma covers the operations of this block, not those of functions it calls)
+    const float den = ray.x * plane.x + ray.y * plane.y + ray.z * plane.z;
+    if (fabsf(den) < 0.000001f) return false;
+    const float num = (v0.x - src.x) * plane.x + (v0.y - src.y) * plane.y + (v0.z - src.z) * plane.z;
+    plane_dist = num / den;
+    if (plane_dist < near) return false;
+    const F3 in_plane = f3(src.x + ray.x * plane_dist, src.y + ray.y * plane_dist, src.z + ray.z * plane_dist);
+    const uint32_t minor = __float_as_uint(plane.w) & 3u, major = __float_as_uint(plane.w) >> 2;
+    ip_minor = comp(in_plane, minor);
+    ip_major = comp(in_plane, major);
+    return !(ip_minor < guard.x || ip_minor > guard.y || ip_major < guard.z || ip_major > guard.w);
+}
+RT_DEV bool polygon_pretest(F3 v0, float4 plane, float4 guard, F3 src, F3 ray, float near) {
+    float t = 0.0f, a = 0.0f, b = 0.0f;
+    return polygon_front(v0, plane, guard, src, ray, near, t, a, b);
+}
 template <class Ctr>
 RT_DEV bool polygon_test(const float4* __restrict__ vpos, const float4* __restrict__ vnrm, uint32_t first, uint32_t n,
                          F3 v0, float4 plane, float4 guard, F3 src, F3 ray, float near, float& t_out, F3& n_out, Ctr& ctr) {
-    const F3 gn = f3(plane.x, plane.y, plane.z);
-    float den = dot(ray, gn);
-    if (fabsf(den) < 0.000001f) return false;
-    float num = dot(sub(v0, src), gn);
-    float plane_dist = num / den;
-    if (plane_dist < near) return false;
-
-    F3 in_plane = add(src, mul(ray, plane_dist));
+    float plane_dist = 0.0f, ip_minor = 0.0f, ip_major = 0.0f;
+    if (!polygon_front(v0, plane, guard, src, ray, near, plane_dist, ip_minor, ip_major)) return false;
     const uint32_t minor = __float_as_uint(plane.w) & 3u, major = __float_as_uint(plane.w) >> 2;
-    const float ip_minor = comp(in_plane, minor), ip_major = comp(in_plane, major);
-    if (ip_minor < guard.x || ip_minor > guard.y || ip_major < guard.z || ip_major > guard.w) return false;
 
     uint32_t count = 0;
     bool have_fwd = false, have_rev = false;

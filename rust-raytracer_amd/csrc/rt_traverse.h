@@ -963,6 +963,7 @@ static_assert(2u * HIT_CAP <= RT_LANE_WORDS, "the hits move to the lane words fo
 #define RT_WQ_DIRECT 32u  // lanes with a candidate at the same moment from which it is tested on the spot
 #endif
 constexpr uint32_t WQ_CAP = RT_WAVE_QUEUE;  // items per wave
+constexpr uint32_t WQ_KEPT = 64u;           // of which, for polygons: those tested up to their edge loop where they were found
 
 RT_DEV uint32_t lane_index() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -980,7 +981,10 @@ struct HitList {
         wq = wave_queue;
         stride = lane_stride;
         wave0[HIT_CAP * stride + lane] = make_uint2(0u, 0u);
-        if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) *queued() = 0u;  // (lane 0 of the wave may have no ray)
+        if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) {  // (lanes 0 and 1 of the wave may have no ray)
+            *queued() = 0u;
+            *kept() = 0u;
+        }
         __builtin_amdgcn_wave_barrier();
     }
     RT_DEV uint32_t* count_of(uint32_t j) const { return (uint32_t*)(wave0 + HIT_CAP * stride + j); }
@@ -1002,41 +1006,85 @@ struct HitList {
     RT_DEV void offer_shape(float t, uint32_t, uint32_t prim, F3) { put(prim, t); }
 
     // Candidate `item` (KIND 1: entry of poly_rec, 2: of cone_items) of this lane's ray: to the wave's queue; the
-    // lanes that are here together ask for room together.
+    // lanes that are here together ask for room together.  A polygon the queue has no room for is taken up to its
+    // edge loop on the spot (most end there); what is left goes to the queue's last WQ_KEPT words, kept for such.
+    RT_DEV uint32_t* kept() const { return (uint32_t*)(wave0 + HIT_CAP * stride + 1) + 1; }  // (lane 1's spare word)
     template <int KIND, class Ctr>
     RT_DEV void push_item(const DevScene& S, uint32_t item, F3 src, F3 ray, float near, uint32_t ignore, Ctr& ctr) {
+        constexpr uint32_t ROOM = KIND == 1 ? WQ_CAP - WQ_KEPT : WQ_CAP;
         const uint64_t here = __ballot(true);
         const uint32_t n_here = (uint32_t)__popcll(here);
-        uint32_t base = WQ_CAP;
+        uint32_t base = ROOM;
         // (enough lanes with a candidate right now: the test on the spot runs well filled, and costs no queueing)
         if (n_here < RT_WQ_DIRECT && lane == (uint32_t)__builtin_ctzll(here)) base = atomicAdd(queued(), n_here);
         base = __builtin_amdgcn_readfirstlane(base);
         const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
-        if (at < WQ_CAP) {
+        if (at < ROOM) {
             wq[at] = (lane << 26) | item;
+        } else if constexpr (KIND == 1) {
+            const float4 plane = S.poly_rec[item * 4u + 1u], rect = S.poly_rec[item * 4u + 2u], p0 = S.poly_rec[item * 4u + 3u];
+            if (polygon_pretest(from4(p0), plane, rect, src, ray, near)) {
+                const uint64_t left = __ballot(true);
+                uint32_t b2 = 0u;
+                if (lane == (uint32_t)__builtin_ctzll(left)) b2 = atomicAdd(kept(), (uint32_t)__popcll(left));
+                b2 = __builtin_amdgcn_readfirstlane(b2);
+                const uint32_t at2 = b2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(left >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)left, 0u));
+                if (at2 < WQ_KEPT) wq[ROOM + at2] = (lane << 26) | item;
+                else polygon_item<false, true>(S, item, src, ray, near, ignore, *this, ctr);
+            }
         } else {  // no room: on the spot
-            if constexpr (KIND == 1) polygon_item<false, true>(S, item, src, ray, near, ignore, *this, ctr);
-            else cone_item<false>(S, item, src, ray, near, ignore, *this, ctr);
+            cone_item<false>(S, item, src, ray, near, ignore, *this, ctr);
         }
     }
     // The queued tests, by all lanes that are here (every owner is among them: they walked the run together).
     template <int KIND, class Ctr>
     RT_DEV void flush(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Ctr& ctr) {
+        constexpr uint32_t ROOM = KIND == 1 ? WQ_CAP - WQ_KEPT : WQ_CAP;
         __builtin_amdgcn_wave_barrier();
         const uint64_t here = __ballot(true);
         const uint32_t n_here = (uint32_t)__popcll(here);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
         uint32_t total = __builtin_amdgcn_readfirstlane(*queued());
-        total = total < WQ_CAP ? total : WQ_CAP;
+        total = total < ROOM ? total : ROOM;
+        uint32_t extra = 0u;  // polygons: entries of the queue's last words (already past their pretest)
         struct ToOwner {  // what the item tests hand their hit to
             HitList& list;
             uint32_t owner;
             RT_DEV void offer_shape(float t, uint32_t, uint32_t prim, F3) { list.deliver(owner, prim, t); }
         };
-        for (uint32_t first = 0u; first < total; first += n_here) {
+        if constexpr (KIND == 1) {
+            // Polygons: most candidates end before the edge loop (the plane is met outside the polygon's extent), and
+            // the loop is most of the test.  First every candidate up to there, 64 at a time; those left move up to the
+            // front of the queue (never more than were read), and the whole test is run for them alone.
+            uint32_t front = 0u;
+            for (uint32_t first = 0u; first < total; first += n_here) {
+                const uint32_t at = first + rank;
+                const bool mine = at < total;
+                const uint32_t e = wq[mine ? at : 0u];
+                const int owner = (int)(e >> 26);
+                const F3 o_src = f3(__shfl(src.x, owner, 64), __shfl(src.y, owner, 64), __shfl(src.z, owner, 64));
+                const F3 o_ray = f3(__shfl(ray.x, owner, 64), __shfl(ray.y, owner, 64), __shfl(ray.z, owner, 64));
+                const float o_near = __shfl(near, owner, 64);
+                bool keep = false;
+                if (mine) {
+                    const uint32_t i = e & 0x3ffffffu;
+                    const float4 plane = S.poly_rec[i * 4u + 1u], rect = S.poly_rec[i * 4u + 2u], p0 = S.poly_rec[i * 4u + 3u];
+                    keep = polygon_pretest(from4(p0), plane, rect, o_src, o_ray, o_near);
+                }
+                const uint64_t km = __ballot(keep);
+                __builtin_amdgcn_wave_barrier();  // (every lane has read its item before any is overwritten)
+                if (keep) wq[front + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = e;
+                front += (uint32_t)__popcll(km);
+            }
+            __builtin_amdgcn_wave_barrier();
+            total = front;
+            extra = __builtin_amdgcn_readfirstlane(*kept());
+            extra = extra < WQ_KEPT ? extra : WQ_KEPT;
+        }
+        for (uint32_t first = 0u; first < total + extra; first += n_here) {
             const uint32_t at = first + rank;
-            const bool mine = at < total;
-            const uint32_t e = wq[mine ? at : 0u];
+            const bool mine = at < total + extra;
+            const uint32_t e = wq[!mine ? 0u : (at < total ? at : ROOM + (at - total))];
             const int owner = (int)(e >> 26);
             // the owner's ray, from its registers
             const F3 o_src = f3(__shfl(src.x, owner, 64), __shfl(src.y, owner, 64), __shfl(src.z, owner, 64));
@@ -1050,7 +1098,10 @@ struct HitList {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (rank == 0u) *queued() = 0u;
+        if (rank == 0u) {
+            *queued() = 0u;
+            *kept() = 0u;
+        }
         __builtin_amdgcn_wave_barrier();
     }
 };
