@@ -157,6 +157,11 @@ typedef struct rt_options {
     uint32_t serial_schedule; /* nonzero: every kernel of the frame on one stream, all shadow rays in one
                                 launch after the last bounce level, and the per-kernel times of rt_stats
                                 filled (HIP events between the launches).  For measurement: slower */
+    uint32_t leaf_walk;      /* nonzero: every ray walks the partition leaf by leaf, testing a leaf's primitives as
+                                it comes to them (the shape of SpacePartition::intersect, src/space_partition.rs:268-385).
+                                0 (default): scenes with cones or many polygons may first collect all of a ray's hits,
+                                each primitive tested once, and then walk only the sub-trees that hold a hit primitive
+                                -- same image, faster on such scenes */
 } rt_options;
 
 typedef struct rt_stats {
@@ -185,7 +190,9 @@ typedef struct rt_stats {
     double ms_shadow;         /* k_shadow, all levels in one launch */
     double ms_light;          /* k_light */
     /* which instances of the trace kernels the frame ran: the value of their CULL template argument
-     * (0 exhaustive, 1 / 2 culled walk, + 4 lean build, + 8 resident blocks, + 16 nodes in LDS); -1 = none */
+     * (0 exhaustive, 1 / 2 culled walk, + 4 lean build, + 8 resident blocks, + 16 nodes in LDS, + 64 all of a
+     * ray's hits first, then the walk over the sub-trees that hold one; kernel_deep + 32: one launch, k_deep,
+     * for all those levels); -1 = none */
     int32_t kernel_shadow;    /* k_shadow<kernel_shadow, ...> */
     int32_t kernel_deep;      /* k_intersect<false, kernel_deep, ...> of the levels below the camera rays */
     uint64_t workspace_bytes; /* device memory the frame's slot holds for ray pools and shadow queues */
@@ -331,8 +338,9 @@ void rt_camera_basis(const rt_view* view, float* out9);
 
 /* Closest-hit queries through the device traversal (src/space_partition.rs:268);
  * host arrays; ignore[i] = 0xffffffff for none; out_prim[i] = 0xffffffff on a miss.
- * fp_mode may be OR-ed with RT_DEBUG_EXHAUSTIVE (walk leaves without culling). */
+ * fp_mode may be OR-ed with RT_DEBUG_EXHAUSTIVE (walk leaves without culling) and RT_DEBUG_LEAF_WALK. */
 #define RT_DEBUG_EXHAUSTIVE 0x100u
+#define RT_DEBUG_LEAF_WALK 0x200u  /* as rt_options.leaf_walk */
 int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32_t fp_mode, uint64_t n, const float* src,
                        const float* ray, const float* near, const uint32_t* ignore, uint32_t* out_prim,
                        float* out_dist, float* out_normal);

@@ -31,6 +31,7 @@ pub const RT_SHADOW_CLOSEST: u32 = 0;
 pub const RT_SHADOW_EXACT_STOP: u32 = 1;
 pub const RT_SHADOW_ANY_HIT: u32 = 2;
 pub const RT_DEBUG_EXHAUSTIVE: u32 = 0x100;
+pub const RT_DEBUG_LEAF_WALK: u32 = 0x200;
 pub const RT_STATIC_WORKSPACE_BYTES: u32 = 64 << 20;
 
 pub const RT_OP_AABB: u32 = 0;
@@ -176,6 +177,7 @@ pub struct rt_options {
     pub compact_tiles: u32,
     pub shadow_mode: u32,
     pub serial_schedule: u32,
+    pub leaf_walk: u32,
 }
 
 #[repr(C)]

@@ -24,6 +24,7 @@ RT_ERR_INVALID, RT_ERR_DEVICE, RT_ERR_UNSUPPORTED, RT_ERR_BUILD, RT_ERR_PARSE, R
 FP_EXACT, FP_FAST = 0, 1
 SHADOW_CLOSEST, SHADOW_EXACT_STOP, SHADOW_ANY_HIT = 0, 1, 2
 DEBUG_EXHAUSTIVE = 0x100
+DEBUG_LEAF_WALK = 0x200
 KIND_SPHERE, KIND_CONE, KIND_POLYGON = 0, 1, 2
 NO_PRIM = 0xFFFFFFFF
 
@@ -116,7 +117,7 @@ class rt_options(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("min_contribution", C.c_float), ("fp_mode", C.c_uint32),
                 ("tile_rank", C.c_uint32), ("tile_count", C.c_uint32), ("collect_work", C.c_uint32),
                 ("exhaustive_leaves", C.c_uint32), ("compact_tiles", C.c_uint32), ("shadow_mode", C.c_uint32),
-                ("serial_schedule", C.c_uint32)]
+                ("serial_schedule", C.c_uint32), ("leaf_walk", C.c_uint32)]
 
 
 class rt_stats(C.Structure):
@@ -383,11 +384,12 @@ class RenderOptions:
     compact_tiles: bool = False      # True: compact tile buffer as output even for a single rank
     shadow_mode: int = 0             # SHADOW_CLOSEST (reference), SHADOW_EXACT_STOP (same image), SHADOW_ANY_HIT (not parity)
     serial_schedule: bool = False    # True: one stream, one shadow launch, per-kernel times in rt_stats (measurement)
+    leaf_walk: bool = False          # True: never the hit-list walk (all hits of a ray first, then the sub-trees that hold one); same image
 
     def c(self):
         return rt_options(self.max_depth, self.min_contribution, self.fp_mode, self.tile_rank, self.tile_count,
                           int(self.collect_work), int(self.exhaustive_leaves), int(self.compact_tiles),
-                          int(self.shadow_mode), int(self.serial_schedule))
+                          int(self.shadow_mode), int(self.serial_schedule), int(self.leaf_walk))
 
 
 class Scene:

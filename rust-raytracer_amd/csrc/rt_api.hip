@@ -846,6 +846,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     FrameArgs A;
     memset(&A, 0, sizeof(A));
     A.scene = scene->dev;
+    if (opt->leaf_walk != 0u) A.scene.hit_walk = 0u;
     const Camera cam = camera_basis(*view);
     memcpy(A.from, view->from, 12);
     memcpy(A.fwd, cam.forward, 12);
@@ -946,7 +947,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     // against 4.72 with four in flight).
     // (The per-level launches of the hit-list walk are one-wave blocks that take twice the time of its one
     // launch for all levels, rings 4: 15.3 against 8.0 ms: those scenes keep the one launch whatever is in flight.)
-    const bool fused = !work && cull && ctx->fuse_deep && !(f.one_stream && !serial && scene->dev.hit_walk == 0u) &&
+    const bool fused = !work && cull && ctx->fuse_deep && !(f.one_stream && !serial && A.scene.hit_walk == 0u) &&
                        (fast ? rt_fast::can_fuse(A, last_level) : rt_exact::can_fuse(A, last_level));
     const int hm = fused ? 1 : 0;  // which set of level sizes applies
     const bool hinted = ctx->hint_valid[hm] && ctx->hint_scene == scene->serial && ctx->hint_slots == n_slots && ctx->hint_depth == opt->max_depth;
@@ -1589,9 +1590,11 @@ extern "C" int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32
                                   uint32_t* out_prim, float* out_dist, float* out_normal) {
     if (!ctx || !scene || !src || !ray || !near || !ignore || !out_prim || !out_dist || !out_normal)
         return fail(ctx, RT_ERR_INVALID, "null argument");
-    const uint32_t fp_mode = fp_mode_flags & ~RT_DEBUG_EXHAUSTIVE;
+    const uint32_t fp_mode = fp_mode_flags & ~(RT_DEBUG_EXHAUSTIVE | RT_DEBUG_LEAF_WALK);
     if (fp_mode > RT_FP_FAST) return fail(ctx, RT_ERR_INVALID, "unknown fp_mode");
     if (n == 0) return RT_OK;
+    DevScene dev = scene->dev;
+    if ((fp_mode_flags & RT_DEBUG_LEAF_WALK) != 0u) dev.hit_walk = 0u;
     for (uint64_t i = 0; i < n; ++i)
         if (ignore[i] != 0xffffffffu && ignore[i] >= scene->data.primitives.size())
             return fail(ctx, RT_ERR_INVALID, "ignore index out of range");
@@ -1612,9 +1615,9 @@ extern "C" int rt_debug_intersect(rt_context* ctx, const rt_scene* scene, uint32
     RT_HIP(ctx, hipMemcpy(d_near.p, near, n * 4, hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(d_ign.p, ignore, n * 4, hipMemcpyHostToDevice));
     if (fp_mode == RT_FP_FAST)
-        RT_HIP(ctx, rt_fast::launch_debug_intersect(scene->dev, (fp_mode_flags & RT_DEBUG_EXHAUSTIVE) == 0, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
+        RT_HIP(ctx, rt_fast::launch_debug_intersect(dev, (fp_mode_flags & RT_DEBUG_EXHAUSTIVE) == 0, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
     else
-        RT_HIP(ctx, rt_exact::launch_debug_intersect(scene->dev, (fp_mode_flags & RT_DEBUG_EXHAUSTIVE) == 0, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
+        RT_HIP(ctx, rt_exact::launch_debug_intersect(dev, (fp_mode_flags & RT_DEBUG_EXHAUSTIVE) == 0, n, d_src.p, d_ray.p, d_near.p, d_ign.p, d_prim.p, d_dist.p, d_nrm.p, nullptr));
     RT_HIP(ctx, hipDeviceSynchronize());
     RT_HIP(ctx, hipMemcpy(out_prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
     RT_HIP(ctx, hipMemcpy(out_dist, d_dist.p, n * 4, hipMemcpyDeviceToHost));

@@ -64,7 +64,8 @@ def test_closest_hit_matches_oracle(rtamd, oracle, spd, gpu_ctx, name):
     rng = np.random.default_rng(7 + SEED_SHIFT)
     src, d, near, ignore = make_rays(rng, 30000, lo, hi, o.info.n_prims)
     wp, wd, wn = o.intersect_rays(src, d, near, ignore)
-    for flags in (0, rtamd.DEBUG_EXHAUSTIVE):
+    # (0: the library's choice of walk -- all hits first where the scene offers that; then leaf by leaf; then exhaustive)
+    for flags in (0, rtamd.DEBUG_LEAF_WALK, rtamd.DEBUG_EXHAUSTIVE):
         gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | flags)
         assert np.array_equal(gp, wp)
         assert np.array_equal(bits(gd), bits(wd))
@@ -137,6 +138,8 @@ def test_leaf_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset)
     gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
     assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    lp, ld, ln = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_LEAF_WALK)  # (the culled walk, leaf by leaf)
+    assert np.array_equal(lp, wp) and np.array_equal(bits(ld), bits(wd)) and np.array_equal(bits(ln), bits(wn))
     hit = wp != 0xFFFFFFFF
     assert SEED_SHIFT or 0.2 < (hit & (wp != 0)).mean() < 0.98  # both sphere hits and misses are exercised
 
@@ -221,6 +224,8 @@ def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offs
     gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
     assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    lp, ld, ln = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_LEAF_WALK)  # (the culled walk, leaf by leaf)
+    assert np.array_equal(lp, wp) and np.array_equal(bits(ld), bits(wd)) and np.array_equal(bits(ln), bits(wn))
     hit = wp != 0xFFFFFFFF
     # (at the 1e-3 scale most polygons fail the reference's |ray . normal| >= 1e-6 test: few hits)
     assert SEED_SHIFT or 0.05 < (hit & (wp != 0)).mean() < 0.98
@@ -319,6 +324,8 @@ def test_cylinder_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, off
     gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
     assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    lp, ld, ln = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_LEAF_WALK)  # (the culled walk, leaf by leaf)
+    assert np.array_equal(lp, wp) and np.array_equal(bits(ld), bits(wd)) and np.array_equal(bits(ln), bits(wn))
     hit = wp != 0xFFFFFFFF
     assert SEED_SHIFT or 0.05 < (hit & (wp != 0)).mean() < 0.98
     fp, fd, fn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_FAST | rtamd.DEBUG_EXHAUSTIVE)
@@ -351,4 +358,6 @@ def test_lanes_with_and_without_the_cylinder_walk_share_a_leaf(rtamd, oracle, gp
     gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
     assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
     assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn))
+    lp, ld, ln = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_LEAF_WALK)  # (the culled walk, leaf by leaf)
+    assert np.array_equal(lp, wp) and np.array_equal(bits(ld), bits(wd)) and np.array_equal(bits(ln), bits(wn))
     assert SEED_SHIFT or (wp != 0xFFFFFFFF).mean() > 0.5

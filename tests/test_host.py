@@ -41,7 +41,7 @@ def test_struct_sizes_match_header(rtamd):
     assert C.sizeof(rtamd.rt_kd_node) == 64
     assert C.sizeof(rtamd.rt_view) == 52
     assert C.sizeof(rtamd.rt_surface) == 40
-    assert C.sizeof(rtamd.rt_options) == 40
+    assert C.sizeof(rtamd.rt_options) == 44
 
 
 def scene_texts(spd):
