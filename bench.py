@@ -353,7 +353,8 @@ def main():
     headline = (args.scene, args.size, W, H) == ("balls", 4, 3840, 2160)
     # the kernel instances the library launched for this scene (rt_stats of the serial-schedule frames)
     k_shadow_name = f"k_shadow<{serial[-1].kernel_shadow}, NoCounters>"
-    k_deep_name = f"k_intersect<false, {serial[-1].kernel_deep}, NoCounters>"
+    kd = serial[-1].kernel_deep  # (+ 32: one launch, k_deep, for all levels below the camera rays)
+    k_deep_name = "none" if kd < 0 else (f"k_deep<{kd - 32}, NoCounters>" if kd & 32 else f"k_intersect<false, {kd}, NoCounters>")
     def flops_of(w):
         return sum(w.get(k, 0.0) * (c - FLOP_SAVED.get(k, 0)) for k, c in FLOP.items())
     flops = flops_of(work)
@@ -417,7 +418,8 @@ def main():
             # neither "hbm" nor "mfma" binds this path (no dense contraction; scene data is cache resident):
             # vector issue with few waves ready per SIMD does.  The HBM view is alongside.
             "bound": "valu",
-            "kernel": k_shadow_name + " (CULL: 2 = culled walk, + 4 lean build, + 8 resident blocks, + 16 nodes in LDS); deeper levels: " + k_deep_name,
+            "kernel": k_shadow_name + " (CULL: 2 = culled walk, + 4 lean build, + 8 resident blocks, + 16 nodes in LDS, + 64 hit-list walk: all of a "
+                      "ray's hits first, then the sub-trees that hold one); deeper levels: " + k_deep_name,
             "achieved": round(sh_flops / sh_s / 1e12, 4),
             "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s",

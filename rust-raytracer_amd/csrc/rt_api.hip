@@ -592,7 +592,11 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     std::vector<uint32_t> prim_entry;
     bool hit_walk = !lean_scene && sd.primitives.size() > 0 && sd.primitives.size() < (1u << 29) &&
                     sc->tree.nodes.size() < (1u << HITWALK_NODE_BITS);
-    if (const char* e = getenv("RTAMD_HIT_WALK")) hit_walk = hit_walk && atoi(e) != 0;
+    bool force_hit_walk = false;  // (experiment, RTAMD_HIT_WALK=2: also scenes of spheres alone, which then run the general kernels)
+    if (const char* e = getenv("RTAMD_HIT_WALK")) {
+        hit_walk = hit_walk && atoi(e) != 0;
+        if (atoi(e) == 2 && sd.primitives.size() > 0) hit_walk = force_hit_walk = true;
+    }
     if (hit_walk) {
         const uint32_t np = (uint32_t)sd.primitives.size();
         pboxes.resize((size_t)np * 2);
@@ -720,7 +724,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
     // lean: no cones and next to no polygons (a floor): kernels without the code for either's records
     d.bnd_records = (uint32_t)(bnd.size() / 4);
-    d.lean = (lean_scene && d.stack_depth <= RT_STACK_RING &&
+    d.lean = (lean_scene && !force_hit_walk && d.stack_depth <= RT_STACK_RING &&
               bnd.size() * sizeof(float) <= RT_LEAN_RECORD_BYTES) ? 1u : 0u;
     d.n_nodes = (uint32_t)sc->tree.nodes.size();
     d.hit_walk = hit_walk ? 1u : 0u;
