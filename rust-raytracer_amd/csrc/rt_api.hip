@@ -728,6 +728,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
               bnd.size() * sizeof(float) <= RT_LEAN_RECORD_BYTES) ? 1u : 0u;
     d.n_nodes = (uint32_t)sc->tree.nodes.size();
     d.hit_walk = hit_walk ? 1u : 0u;
+    d.hit_walk_level0 = (hit_walk && (uint64_t)sc->tree.info.max_leaf * 4u >= sd.primitives.size()) ? 1u : 0u;
     d.prim_box = sc->prim_box.p;
     d.prim_entry = sc->prim_entry.p;
     d.all_w = all_rec[0].x;

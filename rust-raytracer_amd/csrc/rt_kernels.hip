@@ -1122,10 +1122,13 @@ static uint32_t g_cus = 256;  // compute units of the device (init_kernels)
 constexpr int GEN_ID = 2 | 8 | 16, GEN_SH = 2 | 8 | 16;
 constexpr int HITS_ID = 2 | 64, HITS_SH = 2 | 64;  // the hit-list walk (DevScene::hit_walk): deeper levels, shadow rays
 constexpr int HITS_I0 = 1 | 64;                   // ... and camera rays
-// Measured at 3840x2160 (level 0, ms, leaf by leaf / hit list): rings 4 1.19 / 1.25, mount 8 2.00 / 1.97, lathe 96 at
-// 1920x1080 1.06 / 1.12 -- camera rays are coherent, their leaf-by-leaf walk loses little: not used.
+// Camera rays (level 0) by the hit-list walk: only where the partition hardly partitions (DevScene::hit_walk_level0,
+// set when the largest leaf holds a quarter of the primitives or more).  Camera rays are coherent and mostly end in
+// their first leaf; the hit-list walk looks at their whole line.  Measured at 3840x2160 (level 0, ms, leaf by leaf /
+// hit list): mount 8 (largest leaf 45,685 of 131,076) 2.01 / 1.77, at 7680x4320 5.51 / 5.27; rings 4 (212 of 604) 1.18 /
+// 1.20; lathe 96 at 1920x1080 (273 of 6,401) 1.02 / 1.06; tetra 6 at 7680x4320 (252 of 4,096) 4.8 / 7.2.
 #ifndef RT_HITS_LEVEL0
-#define RT_HITS_LEVEL0 0
+#define RT_HITS_LEVEL0 1
 #endif
 constexpr int LEAN_I0 = 5 | (RT_STAY_LEVEL0 ? 8 : 0), LEAN_ID = 6 | (RT_STAY_DEEP ? 8 : 0), LEAN_SH = 6 | (RT_STAY_SHADOW ? 8 : 0);
 static const bool g_lean_stays[5] = {RT_STAY_LEVEL0 != 0, RT_STAY_DEEP != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0, RT_STAY_SHADOW != 0};
@@ -1240,7 +1243,7 @@ hipError_t init_kernels() {
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant) {
     const bool lean = A.scene.lean != 0;
     const uint32_t which = level == 0 ? 0u : 1u;
-    const bool hit_walk = cull && !lean && A.scene.hit_walk != 0u && (level > 0 || RT_HITS_LEVEL0 != 0);
+    const bool hit_walk = cull && !lean && A.scene.hit_walk != 0u && (level > 0 || (RT_HITS_LEVEL0 != 0 && A.scene.hit_walk_level0 != 0u));
     const bool gen_stays = !work && cull && !lean && !hit_walk && A.scene.nodes_lds != 0u && level > 0 && RT_STAY_GEN_DEEP != 0;
     const bool stays = gen_stays || (!work && cull && lean && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
