@@ -273,6 +273,7 @@ def main():
             dist.all_reduce(o_rays, op=dist.ReduceOp.SUM)
         orbit = {"step_wall": float(o_elapsed.item()) / args.steps * 1e3, "retries": int(sum(s.retries for s in o_stats)),
                  "rays_per_frame_mean": float(o_rays.item()) / args.steps,
+                 "device_frame_ms": [round(s.ms_frame, 2) for s in o_stats],  # (each frame's first launch -> framebuffer complete)
                  "mrays_per_s": float(o_rays.item()) / float(o_elapsed.item()) / 1e6}
         # (back to the fixed view for what follows)
         scene.render_device(opt, None, (mine if tiled else image).data_ptr(), stream)

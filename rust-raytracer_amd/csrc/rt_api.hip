@@ -1244,8 +1244,13 @@ int begin_frame(rt_context* ctx, const rt_scene* scene, const rt_view* view, con
     // that size, or to come close.
     const bool proven = ctx->hint_scene == scene->serial && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth;
     const size_t floor_cap = std::max<size_t>((size_t)p.n_slots * 2, 1u << 16);
-    const size_t cap = std::max(std::max(f.ws.pool_cap, proven ? ctx->want_pool : 0), floor_cap);
-    const size_t scap = std::max(std::max(f.ws.shadow_cap / p.lights1, proven ? ctx->want_shadow1 : 0), floor_cap);
+    // (The wanted sizes carry a quarter of headroom and creep up with every frame that needs a little more than
+    // any before -- a camera going round a scene.  A slot that holds all but an eighth of them keeps its pools:
+    // growing them means freeing them, which waits for everything in flight on the device.  lathe 96 at 1920x1080,
+    // twenty views round the scene with four frames in flight: 3.6 -> 1.8 ms per frame.)
+    auto wanted = [&](size_t have, size_t want) { return proven && have < want - want / 8 ? want : have; };
+    const size_t cap = std::max(wanted(f.ws.pool_cap, ctx->want_pool), floor_cap);
+    const size_t scap = std::max(wanted(f.ws.shadow_cap / p.lights1, ctx->want_shadow1), floor_cap);
     // Any other frame is waited for here, pools grown and the frame re-run as often as it takes, so that
     // what the caller queues on `stream` after this call finds the finished image.
     rc = enqueue_frame(ctx, f, p, cap, scap);
