@@ -157,11 +157,15 @@ typedef struct rt_options {
     uint32_t serial_schedule; /* nonzero: every kernel of the frame on one stream, all shadow rays in one
                                 launch after the last bounce level, and the per-kernel times of rt_stats
                                 filled (HIP events between the launches).  For measurement: slower */
-    uint32_t leaf_walk;      /* nonzero: every ray walks the partition leaf by leaf, testing a leaf's primitives as
+    uint32_t leaf_walk;      /* 1: every ray walks the partition leaf by leaf, testing a leaf's primitives as
                                 it comes to them (the shape of SpacePartition::intersect, src/space_partition.rs:268-385).
                                 0 (default): scenes with cones or many polygons may first collect all of a ray's hits,
                                 each primitive tested once, and then walk only the sub-trees that hold a hit primitive
-                                -- same image, faster on such scenes */
+                                -- same image, faster on such scenes; whether their camera rays do so, 64 at a time
+                                (the rays of an 8x8 tile leave one point: what none of them can pass is looked at
+                                once for all), or go leaf by leaf is decided by timing the first two frames of a
+                                scene at an image size, one each way.  2: no timing, camera rays by the tile.
+                                All give the same image */
 } rt_options;
 
 typedef struct rt_stats {

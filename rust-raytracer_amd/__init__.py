@@ -384,7 +384,7 @@ class RenderOptions:
     compact_tiles: bool = False      # True: compact tile buffer as output even for a single rank
     shadow_mode: int = 0             # SHADOW_CLOSEST (reference), SHADOW_EXACT_STOP (same image), SHADOW_ANY_HIT (not parity)
     serial_schedule: bool = False    # True: one stream, one shadow launch, per-kernel times in rt_stats (measurement)
-    leaf_walk: bool = False          # True: never the hit-list walk (all hits of a ray first, then the sub-trees that hold one); same image
+    leaf_walk: int = 0               # 1 / True: never the hit-list walk (all hits of a ray first, then the sub-trees that hold one); 2: camera rays always by the tile's beam, no timing of the first frames; same image
 
     def c(self):
         return rt_options(self.max_depth, self.min_contribution, self.fp_mode, self.tile_rank, self.tile_count,

@@ -114,6 +114,13 @@ struct FrameSlot {
     void* out_u8 = nullptr;
     hipStream_t caller = nullptr;
     int variant_deep = -1, variant_shadow = -1;  // CULL values of the kernel instances this frame launched
+    // Camera rays of a scene with the hit-list tables whose tree partitions well (choose_level0): which way this
+    // frame's go (0 leaf by leaf, 1 by the wave's beam where that is cheap), whether the frame is one of the two that
+    // are timed to find out, and the events round its level-0 launch.
+    int l0_variant = 0;
+    bool l0_trial = false;
+    uint32_t l0_epoch = 0;
+    hipEvent_t ev_l0[2] = {nullptr, nullptr};
     // A context over several devices: the frame of ticket t uses slot t of every rank's context.  Each
     // rank's slot has its own compact tile buffers (the root's: the gathered buffers), the stream its
     // share of the frame ends on and its copy to the root runs on, and the event that ends both.
@@ -163,6 +170,14 @@ struct rt_context {
     // ([1]: of frames whose deeper levels ran as one launch -- there "level 2" stands for all levels from 2 on)
     uint32_t hint_rays[2][RT_MAX_LEVELS] = {}, hint_lit[2][RT_MAX_LEVELS] = {};
     bool hint_valid[2] = {false, false};
+    // Which way camera rays go (FrameSlot::l0_variant) is measured, per scene, image share and arithmetic mode: the
+    // first frame of a kind goes one way, the second the other, each alone on the device with its level-0 launch
+    // timed, and the frames after them the faster way.  (Both ways give the same image.)
+    int beam_level0 = 1;  // RTAMD_BEAM_LEVEL0: 0 never the beam, 1 measured, 2 always
+    uint64_t l0_scene = 0;
+    uint32_t l0_slots = 0, l0_mode = 0, l0_epoch = 0;
+    float l0_ms[2] = {-1.0f, -1.0f};
+    bool l0_pending[2] = {false, false};
 };
 
 static std::atomic<uint64_t> g_scene_serial{0};
@@ -299,6 +314,7 @@ int setup_slot(rt_context* ctx, FrameSlot& f) {
     RT_HIP(ctx, hipStreamCreateWithFlags(&f.gather_stream, hipStreamNonBlocking));
     RT_HIP(ctx, hipEventCreateWithFlags(&f.ev_gather, hipEventDisableTiming));
     for (auto& e : f.ev_t) RT_HIP(ctx, hipEventCreate(&e));
+    for (auto& e : f.ev_l0) RT_HIP(ctx, hipEventCreate(&e));
     RT_HIP(ctx, hipHostMalloc((void**)&f.h_levels, LV_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     RT_HIP(ctx, hipHostMalloc((void**)&f.h_counters, N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault));
     return RT_OK;
@@ -316,6 +332,8 @@ void teardown_slot(FrameSlot& f) {
     if (f.ev_gather) (void)hipEventDestroy(f.ev_gather);
     if (f.gather_stream) (void)hipStreamDestroy(f.gather_stream);
     for (auto& e : f.ev_t)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : f.ev_l0)
         if (e) (void)hipEventDestroy(e);
     if (f.h_levels) (void)hipHostFree(f.h_levels);
     if (f.h_counters) (void)hipHostFree(f.h_counters);
@@ -354,6 +372,7 @@ extern "C" int rt_context_create(int n_devices, const int* device_ids, rt_contex
         f.ws.counters = f.counters.p;
     }
     if (const char* s = getenv("RTAMD_FUSE_DEEP")) ctx->fuse_deep = strtoul(s, nullptr, 10) != 0;
+    if (const char* s = getenv("RTAMD_BEAM_LEVEL0")) ctx->beam_level0 = (int)strtoul(s, nullptr, 10);
     if (const char* s = getenv("RTAMD_DEEP_EXIT_POLLS")) ctx->deep_exit_polls = (uint32_t)strtoul(s, nullptr, 10);
     if (const char* s = getenv("RTAMD_WORKSPACE_MAX_MB")) ctx->workspace_limit = (uint64_t)strtoull(s, nullptr, 10) << 20;
     // The entry point that allocates nothing works in the static array: this device's copy of it
@@ -729,6 +748,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.n_nodes = (uint32_t)sc->tree.nodes.size();
     d.hit_walk = hit_walk ? 1u : 0u;
     d.hit_walk_level0 = (hit_walk && (uint64_t)sc->tree.info.max_leaf * 4u >= sd.primitives.size()) ? 1u : 0u;
+    if (const char* e = getenv("RTAMD_HIT_LEVEL0")) d.hit_walk_level0 = (hit_walk && atoi(e) != 0) ? 1u : 0u;  // (experiment)
     d.prim_box = sc->prim_box.p;
     d.prim_entry = sc->prim_entry.p;
     d.all_w = all_rec[0].x;
@@ -815,6 +835,38 @@ int plan_frame(rt_context* ctx, const FrameSlot& f, FramePlan& p) {
 // Nothing here waits for the GPU.  The kernels run on the slot's own stream; only the last one
 // (resolve of level 0, the one that writes the caller's buffers) is ordered after what the
 // caller's stream held when the frame began, and the caller's stream then waits for the frame.
+// Which way the camera rays of the frame in slot `f` go, and whether the frame is timed for it (rt_context::l0_ms).
+void choose_level0(rt_context* ctx, FrameSlot& f, const FramePlan& p) {
+    f.l0_variant = 0;
+    f.l0_trial = false;
+    const DevScene& d = f.scene->dev;
+    const rt_options& o = f.opt;
+    if (ctx->beam_level0 == 0 || o.collect_work != 0 || o.exhaustive_leaves != 0 || o.leaf_walk == 1u || d.lean != 0u || d.hit_walk == 0u ||
+        d.hit_walk_level0 != 0u)
+        return;
+    if (ctx->beam_level0 >= 2 || o.leaf_walk == 2u) {
+        f.l0_variant = 1;
+        return;
+    }
+    if (ctx->l0_scene != f.scene->serial || ctx->l0_slots != p.n_slots || ctx->l0_mode != o.fp_mode) {
+        ctx->l0_scene = f.scene->serial;
+        ctx->l0_slots = p.n_slots;
+        ctx->l0_mode = o.fp_mode;
+        ctx->l0_ms[0] = ctx->l0_ms[1] = -1.0f;
+        ctx->l0_pending[0] = ctx->l0_pending[1] = false;
+        ++ctx->l0_epoch;
+    }
+    f.l0_epoch = ctx->l0_epoch;
+    for (int v = 0; v < 2; ++v)
+        if (ctx->l0_ms[v] < 0.0f && !ctx->l0_pending[v]) {
+            f.l0_variant = v;
+            f.l0_trial = true;
+            ctx->l0_pending[v] = true;
+            return;
+        }
+    f.l0_variant = (ctx->l0_ms[0] >= 0.0f && ctx->l0_ms[1] >= 0.0f && ctx->l0_ms[1] < ctx->l0_ms[0]) ? 1 : 0;
+}
+
 int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap, size_t scap) {
     const rt_scene* scene = f.scene;
     const rt_view* view = &f.view;
@@ -851,7 +903,8 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     FrameArgs A;
     memset(&A, 0, sizeof(A));
     A.scene = scene->dev;
-    if (opt->leaf_walk != 0u) A.scene.hit_walk = 0u;
+    if (opt->leaf_walk == 1u) A.scene.hit_walk = 0u;
+    if (A.scene.hit_walk != 0u && A.scene.hit_walk_level0 == 0u && f.l0_variant == 1) A.scene.hit_walk_level0 = 2u;  // (2: the beam, or leaf by leaf)
     const Camera cam = camera_basis(*view);
     memcpy(A.from, view->from, 12);
     memcpy(A.fwd, cam.forward, 12);
@@ -974,7 +1027,9 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.fused = fused ? 1u : 0u;
     f.fused = fused;
     if (fused) {
+        if (f.l0_trial) RT_HIP(ctx, hipEventRecord(f.ev_l0[0], st));
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, 0, work, cull, grid0, st, nullptr) : rt_exact::launch_intersect(A, 0, work, cull, grid0, st, nullptr));
+        if (f.l0_trial) RT_HIP(ctx, hipEventRecord(f.ev_l0[1], st));
         if (serial) RT_HIP(ctx, hipEventRecord(f.ev_t[0], st));
         if (n_lights) {
             RT_HIP(ctx, hipEventRecord(f.ev_level[0], st));
@@ -1002,7 +1057,9 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     for (uint32_t level = 0; level <= last_level && !fused; ++level) {
         const uint32_t g = level == 0 ? grid0 : blocks_for(ctx->hint_rays[hm][level], gridn);
         int* variant = level > 0 ? &f.variant_deep : nullptr;
+        if (level == 0 && f.l0_trial) RT_HIP(ctx, hipEventRecord(f.ev_l0[0], st));
         RT_HIP(ctx, fast ? rt_fast::launch_intersect(A, level, work, cull, g, st, variant) : rt_exact::launch_intersect(A, level, work, cull, g, st, variant));
+        if (level == 0 && f.l0_trial) RT_HIP(ctx, hipEventRecord(f.ev_l0[1], st));
         if (serial) {
             RT_HIP(ctx, hipEventRecord(f.ev_t[level], st));
             f.timed_levels = level + 1;
@@ -1126,6 +1183,15 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
             ctx->hint_rays[hm][l] = l <= opt->max_depth ? lv[l] : 0u;
             ctx->hint_lit[hm][l] = l <= opt->max_depth ? lv[LV_SHADOW_COUNT + l] : 0u;
         }
+        if (f.l0_trial) {
+            f.l0_trial = false;
+            if (f.l0_epoch == ctx->l0_epoch) {
+                float ms = 0;
+                RT_HIP(ctx, hipEventElapsedTime(&ms, f.ev_l0[0], f.ev_l0[1]));
+                ctx->l0_ms[f.l0_variant] = ms;
+                ctx->l0_pending[f.l0_variant] = false;
+            }
+        }
         stats.kernel_shadow = f.variant_shadow;
         stats.kernel_deep = f.variant_deep;
         stats.workspace_bytes = (uint64_t)f.ws.pool_cap * NODE_BYTES + (uint64_t)f.ws.shadow_cap * SHADOW_BYTES;
@@ -1242,7 +1308,9 @@ int begin_frame(rt_context* ctx, const rt_scene* scene, const rt_view* view, con
     // times the number of lights.
     // A frame like the last finished one (same scene, image share and depth) is known to fit pools of
     // that size, or to come close.
-    const bool proven = ctx->hint_scene == scene->serial && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth;
+    choose_level0(ctx, f, p);
+    // (a frame whose camera rays are timed runs alone: it is waited for like one of unproven size)
+    const bool proven = ctx->hint_scene == scene->serial && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth && !f.l0_trial;
     const size_t floor_cap = std::max<size_t>((size_t)p.n_slots * 2, 1u << 16);
     // (The wanted sizes carry a quarter of headroom and creep up with every frame that needs a little more than
     // any before -- a camera going round a scene.  A slot that holds all but an eighth of them keeps its pools:
@@ -1356,6 +1424,7 @@ extern "C" int rt_render_device_static(rt_context* ctx, const rt_scene* scene, c
     ws.pool_cap = cap;
     ws.shadow_cap = cap * p.lights1;
     if ((size_t)(at - ctx->scratch_ptr) > RT_STATIC_WORKSPACE_BYTES) return fail(ctx, RT_ERR_CAPACITY, "static workspace layout");
+    choose_level0(ctx, f, p);
     rc = enqueue_frame(ctx, f, p, cap, cap);
     if (rc != RT_OK) return rc;
     f.busy = true;

@@ -690,12 +690,15 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
         Hit blocker;
         bool blocked = false;
         bool found;
-        if constexpr ((CULL & 64) != 0)
-            found = kd_traverse_hits<CULL & 3, true>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), blocker,
-                                                     lds_stack, ctr, so.w);
-        else
+        if constexpr ((CULL & 64) != 0) {
+            const float4 lp = S.lights[((CULL & 8) != 0 ? (uint32_t)(i / A.shadow_cap) : blockIdx.y) * 2u];  // (one light's rays per wave)
+            found = kd_traverse_hits<CULL & 3, true, Ctr, (CULL & 128) != 0 ? 2 : 0>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f,
+                                                                                   __float_as_uint(sd.w), blocker, lds_stack, ctr, so.w,
+                                                                                   f3(lp.x, lp.y, lp.z));
+        } else {
             found = kd_traverse_closest<CULL, Ctr, OCC>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w),
                                                         blocker, lds_stack, ctr, so.w);
+        }
         if (found) blocked = blocker.dist <= so.w;
         A.sray_blocked[i] = blocked ? 1u : 0u;
     };
@@ -1119,9 +1122,16 @@ static uint32_t g_cus = 256;  // compute units of the device (init_kernels)
 #ifndef RT_STAY_GEN_SHADOW
 #define RT_STAY_GEN_SHADOW 1
 #endif
+#ifndef RT_BEAM
+#define RT_BEAM 1
+#endif
+#ifndef RT_BEAM_SHADOW
+#define RT_BEAM_SHADOW 0
+#endif
 constexpr int GEN_ID = 2 | 8 | 16, GEN_SH = 2 | 8 | 16;
-constexpr int HITS_ID = 2 | 64, HITS_SH = 2 | 64;  // the hit-list walk (DevScene::hit_walk): deeper levels, shadow rays
-constexpr int HITS_I0 = 1 | 64;                   // ... and camera rays
+constexpr int HITS_ID = 2 | 64, HITS_SH = 2 | 64 | (RT_BEAM_SHADOW ? 128 : 0);  // the hit-list walk (DevScene::hit_walk): deeper levels, shadow rays (+ 128: beam_runs, towards the light)
+constexpr int HITS_I0L = 1 | 64 | 128 | 256;  // camera rays of the other scenes with the hit-list tables: by the wave where that is cheap, else leaf by leaf
+constexpr int HITS_I0 = 1 | 64 | (RT_BEAM ? 128 : 0);  // ... and camera rays (+ 128: a wave's rays leave one point, beam_runs)
 // Camera rays (level 0) by the hit-list walk: only where the partition hardly partitions (DevScene::hit_walk_level0,
 // set when the largest leaf holds a quarter of the primitives or more).  Camera rays are coherent and mostly end in
 // their first leaf; the hit-list walk looks at their whole line.  Measured at 3840x2160 (level 0, ms, leaf by leaf /
@@ -1186,6 +1196,9 @@ hipError_t init_kernels() {
 #if RT_HITS_LEVEL0
                          (const void*)k_intersect<true, HITS_I0, NoCounters>, (const void*)k_intersect<true, HITS_I0, WorkCounters>,
 #endif
+#if RT_BEAM
+                         (const void*)k_intersect<true, HITS_I0L, NoCounters>,
+#endif
                          (const void*)k_shadow<HITS_SH, NoCounters>, (const void*)k_shadow<HITS_SH, WorkCounters>,
                          (const void*)k_deep<HITS_ID, NoCounters>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>, (const void*)k_debug_intersect<HITS_ID>};
@@ -1243,17 +1256,22 @@ hipError_t init_kernels() {
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant) {
     const bool lean = A.scene.lean != 0;
     const uint32_t which = level == 0 ? 0u : 1u;
-    const bool hit_walk = cull && !lean && A.scene.hit_walk != 0u && (level > 0 || (RT_HITS_LEVEL0 != 0 && A.scene.hit_walk_level0 != 0u));
+    const bool beam_or_leaf = RT_BEAM != 0 && !work && cull && !lean && level == 0 && A.scene.hit_walk != 0u && A.scene.hit_walk_level0 == 2u;
+    const bool hit_walk = cull && !lean && A.scene.hit_walk != 0u && (level > 0 || beam_or_leaf || (RT_HITS_LEVEL0 != 0 && A.scene.hit_walk_level0 == 1u));
     const bool gen_stays = !work && cull && !lean && !hit_walk && A.scene.nodes_lds != 0u && level > 0 && RT_STAY_GEN_DEEP != 0;
     const bool stays = gen_stays || (!work && cull && lean && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
     const dim3 g(blocks_of(grid, tb, stays, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU)), b(tb);
     const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays, hit_walk);
     if (variant) {
-        if (level == 0) *variant = !cull ? 0 : (hit_walk ? HITS_I0 : (!work && lean ? LEAN_I0 : 1));
+        if (level == 0) *variant = !cull ? 0 : (beam_or_leaf ? HITS_I0L : (hit_walk ? HITS_I0 : (!work && lean ? LEAN_I0 : 1)));
         else *variant = !cull ? 0 : (hit_walk ? HITS_ID : (work ? 2 : (lean ? LEAN_ID : (gen_stays ? GEN_ID : 2))));
     }
     if (level == 0) {  // camera rays start outside the scene: the line test alone
+#if RT_BEAM
+        if (beam_or_leaf) hipLaunchKernelGGL((k_intersect<true, HITS_I0L, NoCounters>), g, b, lds, st, A, level);
+        else
+#endif
 #if RT_HITS_LEVEL0
         if (work && hit_walk) hipLaunchKernelGGL((k_intersect<true, HITS_I0, WorkCounters>), g, b, lds, st, A, level);
         else if (hit_walk) hipLaunchKernelGGL((k_intersect<true, HITS_I0, NoCounters>), g, b, lds, st, A, level);
@@ -1403,9 +1421,9 @@ hipError_t launch_debug_intersect(const DevScene& S, bool cull, uint64_t n, cons
 }
 
 #if defined(RT_X_PHASE) && !RT_FAST
-extern "C" int rt_x_hit_stats(unsigned long long* out8, int reset) {
-    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_hitstat), 8 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hitstat), z, sizeof(z)); }
+extern "C" int rt_x_hit_stats(unsigned long long* out16, int reset) {
+    if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_hitstat), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hitstat), z, sizeof(z)); }
     return 0;
 }
 extern "C" int rt_x_phase_cycles(unsigned long long* out8, int reset) {

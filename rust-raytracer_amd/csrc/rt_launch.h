@@ -72,7 +72,8 @@ struct DevScene {
                                // (trees of small leaves, where rays differ most in the number of leaves they visit)
     // The hit-list walk (rt_traverse.h, HitWalk): hit_walk != 0 -> the scene has the tables it needs.
     uint32_t hit_walk;
-    uint32_t hit_walk_level0;  // ... and camera rays take it too (scenes whose largest leaf holds a quarter of the primitives)
+    uint32_t hit_walk_level0;  // camera rays: 1 take it too (scenes whose largest leaf holds a quarter of the primitives); 2 (set
+                               // per frame, rt_api.hip choose_level0): by the wave's beam where that is cheap, else leaf by leaf; 0 leaf by leaf
     uint32_t all_w;            // "leaf" of ALL primitives, each once, list position = primitive index: its record's
     uint4 all_q2, all_q3;      // three words as in `nodes` (runs in the arrays above, behind the real leaves')
     const float4* prim_box;    // 2 per primitive: {corner, -} {fl(corner + extent), -}, src/shape.rs:37-39

@@ -696,7 +696,7 @@ __device__ unsigned long long g_phase[8];
 #define RT_PHASE_END() do {} while (0)
 #endif
 #ifdef RT_X_PHASE  // (the same experiment's counts for the hit-list walk: rays, rays walked leaf by leaf, hits, rays in step (B), its interior steps, its leaves)
-__device__ unsigned long long g_hitstat[8];
+__device__ unsigned long long g_hitstat[16];
 #define RT_HITSTAT(k, v) atomicAdd(&g_hitstat[k], (unsigned long long)(v))
 #else
 #define RT_HITSTAT(k, v) do {} while (0)
@@ -1136,11 +1136,240 @@ template <int CULL, class Ctr, int OCC = 0>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr, float limit = 0.0f);
 
+// ---------------------------------------------------------------------------------------
+// Step (A) for a wave whose 64 rays leave ONE point (camera rays): the bounding records are looked at by the wave,
+// not by every ray.  The rays' lines lie in a narrow cone about the first ray's direction (a unit axis g and the
+// largest angle theta any of the 64 makes with it), and a record {C, q} that no line of that cone can pass is one
+// no ray of the wave can pass: each lane tests ANOTHER record against the cone -- 64 records per step instead of
+// eight per ray -- down to the single entries, and what is left is a short list of candidate entries, which every
+// lane then takes to its own ray in the same order (records and entries arrive once per wave and are handed round
+// from registers; no lane waits for another, because all do the same).
+//   The test.  A record's promise (leaf_cluster.cpp) is, in exact terms: the reference can accept an entry below
+// it only on a line with dist(line, C)^2 <= q + 17 k0^2 |D|^2, D = C - apex.  With rho^2 = q + BEAM_BETA |D|^2
+// (3e-5 against 17 k0^2 = 1.95e-5: the rest is for the roundings of |D|^2 and rho^2), h = sqrt(|D|^2 - rho^2) and
+// psi = asin(rho / |D|), a line through the apex meets that sphere iff its angle with D or -D is at most psi; the
+// cone's lines keep at least max(0, phi - theta) from D, phi the angle between g and D.  So no line of the cone
+// meets it iff |cos phi| < cos(theta + psi), i.e.  |g . D| < cos(theta) h - sin(theta) rho.  Evaluated in f32 with
+// every rounding on the keeping side: |g . D| + 2e-5 |D| on the left (g is unit to 3u, the dot product good to
+// 5u |D|, the right side's products to 2u |D|), h^2 from |D|^2 (1 - 1e-6) (its 4u, and the square root's 1 ulp),
+// cos(theta) rounded down by 1e-6, sin(theta) up by 1e-5 and 1e-6 (the cross product it comes from is good to
+// 3u, the rays' unit directions to 4u).  An apex inside the sphere, or a NaN anywhere, keeps the record.
+// A sphere entry {c, r^2} counts as the record sphere_record() makes of it: q = 1.065 r^2 >= (r (1 + k0))^2 17/16.
+//   The cone is only formed when all 64 lanes carry rays the records can take, from bit-identical origins, within
+// a right angle of the first; otherwise, and when the candidates or the pending records outgrow their LDS words,
+// every lane walks the records for itself as before (nothing has been tested by then).
+// ---------------------------------------------------------------------------------------
+constexpr float BEAM_BETA = 3e-5f;
+#ifndef RT_BEAM_MOST
+#define RT_BEAM_MOST 256           // camera rays of trees that partition well: most candidates a wave takes to its rays
+#endif
+#ifndef RT_BEAM_MAX_SIN
+#define RT_BEAM_MAX_SIN 0.05f      // shadow rays: no beam about rays that spread wider than this (sine of the angle) ...
+#endif
+#ifndef RT_BEAM_MAX_SPREAD
+#define RT_BEAM_MAX_SPREAD 0.1f    // ... or whose origins lie farther apart than this, relative to their distance from the light
+#endif
+constexpr uint32_t BEAM_PENDING = 64u * RT_LANE_WORDS;  // records waiting for their test: the wave's lane words
+struct Beam {
+    F3 apex, axis;
+    float cos_lo, sin_hi;
+    float eps;    // the lines pass the apex within this
+    F3 org;       // one ray's origin, and how far from it the other origins lie at most (a record's slack grows
+    float spread; // with the distance from the ray's OWN origin to the record's centre)
+    float reach;  // what lies farther than this from the apex, on the axis' side, lies behind every origin (inf: nothing does)
+    RT_DEV bool may_hit(float cx, float cy, float cz, float q) const {
+        const float dx = cx - apex.x, dy = cy - apex.y, dz = cz - apex.z;
+        const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const float gd = __builtin_fmaf(axis.z, dz, __builtin_fmaf(axis.y, dy, axis.x * dx));
+        const float sd = __builtin_amdgcn_sqrtf(dd);
+        const float ox = cx - org.x, oy = cy - org.y, oz = cz - org.z;
+        const float e = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox))), 1.000001f, spread);  // >= |origin - C|
+        const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(e * e, BEAM_BETA, q)) + eps;
+        const float h2 = __builtin_fmaf(dd, 0.999999f, -rho * rho);
+        if (!(h2 > 0.0f)) return true;
+        const float rhs = cos_lo * __builtin_amdgcn_sqrtf(h2) - sin_hi * rho;
+        const float slack = sd * 2e-5f;
+        const bool ahead = !(gd + slack < rhs), behind = !(slack - gd < rhs);  // the lines' halves on the axis' side / on the other
+        if (!ahead && !behind) return false;
+        if (!behind && sd - rho > reach) return false;
+        return true;
+    }
+};
+
+RT_DEV uint32_t below_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+// The candidate entries of one run (KIND as leaf_run_lane's), appended to cand[0 .. n_cand) as KIND << 30 | entry.
+// ww: the wave's lane words (word j at ww[(j >> 6) * stride + (j & 63)]).  All 64 lanes; false: no room.
+template <int KIND>
+RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint32_t count, uint32_t header, uint32_t* ww,
+                         uint32_t stride, uint32_t* cand, uint32_t& n_cand, uint32_t lane) {
+    const float4 hf = ld_f4<true>(S.bnd, header), whole = ld_f4<true>(S.bnd, header + 1u);
+    if (!b.may_hit(whole.x, whole.y, whole.z, whole.w)) return true;
+    const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
+                   off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w) & 7u;
+    const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
+    auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : off4)); };
+    auto level_n = [&](uint32_t L) { return L == 0u ? count : (L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : n4))); };
+    auto word = [&](uint32_t j) -> uint32_t& { return ww[(j >> 6) * stride + (j & 63u)]; };
+    const uint32_t n_top = level_n(top);
+    if (n_top > BEAM_PENDING) return false;
+    for (uint32_t i = lane; i < n_top; i += 64u) word(i) = (top << 28) | i;
+    uint32_t size = n_top;
+    while (size != 0u) {
+        const uint32_t n = size < 64u ? size : 64u;
+        size -= n;
+        const uint32_t e = word(size + (lane < n ? lane : 0u));
+        const bool mine = lane < n && e != 0xffffffffu;
+        const uint32_t L = e >> 28, i = e & 0x0fffffffu;
+        float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+        if (mine) {
+            if (L != 0u) {
+                rec = S.bnd[level_off(L) + i];
+            } else if constexpr (KIND == 0) {
+                rec = S.sph[first + i];
+                rec.w *= 1.065f;
+            } else {
+                rec = (KIND == 1 ? S.poly_bound : S.cone_bound)[first + i];
+            }
+        }
+        const bool pass = mine && b.may_hit(rec.x, rec.y, rec.z, rec.w);
+        const uint64_t m_entry = __ballot(pass && L == 0u), m_inner = __ballot(pass && L != 0u);
+        const uint32_t n_entry = (uint32_t)__popcll(m_entry), n_inner = (uint32_t)__popcll(m_inner);
+        if (lane == 0u) RT_HITSTAT(11, n);
+        if (n_cand + n_entry > WQ_CAP || size + 8u * n_inner > BEAM_PENDING) {
+            if (lane == 0u) RT_HITSTAT(n_cand + n_entry > WQ_CAP ? 8 : 9, 1u);
+            return false;
+        }
+        if (pass && L == 0u) cand[n_cand + below_in(m_entry)] = ((uint32_t)KIND << 30) | (first + i);
+        n_cand += n_entry;
+        if (pass && L != 0u) {
+            const uint32_t at = size + 8u * below_in(m_inner), kids = level_n(L - 1u) - 8u * i;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) word(at + k) = k < kids ? (((L - 1u) << 28) | (8u * i + k)) : 0xffffffffu;
+        }
+        size += 8u * n_inner;
+    }
+    return true;
+}
+
+// The three runs of the leaf of all primitives for a wave of rays from one point; false: not done, every lane for itself.
+// live: this lane's ray is inside the root's box (the others take part in the wave's steps and test nothing).
+// TO_APEX false: the rays start at one point (camera rays).  TO_APEX true: they all make for `apex` (shadow rays and
+// their light: a ray's direction is fl(fl(apex - src) / its length), which points at the apex to 3u, and `limit` is
+// that length), from origins of their own; what a ray can hit lies between its origin and the apex, or beyond the apex.
+template <bool TO_APEX, bool BEHIND, class LB, class Ctr>
+RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float near, uint32_t ignore, bool tame, bool live,
+                      LB& hl, Ctr& ctr, uint32_t* lane_words, uint32_t stride, F3 apex, float limit, uint32_t most) {
+    if (__ballot(true) != ~0ull) return false;
+    const uint32_t lane = hl.lane;
+    const uint64_t m_live = __ballot(live);
+    if (m_live == 0ull) return false;
+    const int lead = __builtin_ctzll(m_live);
+    Beam b;
+    const F3 lead_un = f3(__shfl(un.x, lead, 64), __shfl(un.y, lead, 64), __shfl(un.z, lead, 64));
+    bool same = true;
+    if constexpr (TO_APEX) {
+        b.apex = apex;
+        b.axis = f3(-lead_un.x, -lead_un.y, -lead_un.z);  // from the apex towards the origins
+        float far = live ? limit : 0.0f;
+        same = !live || (limit == limit && limit < 1e30f);
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(far, off, 64);
+            far = o > far ? o : far;
+        }
+        b.org = f3(__shfl(src.x, lead, 64), __shfl(src.y, lead, 64), __shfl(src.z, lead, 64));
+        const F3 off = sub(src, b.org);
+        float o2 = live ? dot(off, off) : 0.0f;
+        for (int k = 32; k > 0; k >>= 1) {
+            const float o = __shfl_xor(o2, k, 64);
+            o2 = o > o2 ? o : o2;
+        }
+        b.spread = __builtin_amdgcn_sqrtf(o2) * 1.00001f;
+        if (!(b.spread < far * RT_BEAM_MAX_SPREAD)) {
+            if (lane == 0u) RT_HITSTAT(7, 1u);
+            return false;
+        }
+        b.eps = far * 1e-6f;
+        b.reach = __builtin_fmaf(far, 1.00002f, 1e-30f);  // (>= far + 2 eps)
+    } else {
+        b.apex = f3(__shfl(src.x, lead, 64), __shfl(src.y, lead, 64), __shfl(src.z, lead, 64));
+        b.axis = lead_un;
+        same = src.x == b.apex.x && src.y == b.apex.y && src.z == b.apex.z;
+        b.org = b.apex;
+        b.spread = 0.0f;
+        b.eps = 0.0f;
+        b.reach = INFINITY;
+    }
+    const F3 cr = cross(lead_un, un);
+    float s2 = live ? dot(cr, cr) : 0.0f;
+    const bool ahead = !live || dot(lead_un, un) > 0.0f;
+    if (__ballot(!tame || !same || !ahead) != 0ull) {
+        if (lane == 0u) RT_HITSTAT(7, 1u);
+        return false;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(s2, off, 64);
+        s2 = o > s2 ? o : s2;
+    }
+    b.sin_hi = __builtin_fmaf(__builtin_amdgcn_sqrtf(s2), 1.00001f, 1e-6f);
+    if (!(b.sin_hi < (TO_APEX ? RT_BEAM_MAX_SIN : 0.7f))) {  // (also NaN)
+        if (lane == 0u) RT_HITSTAT(7, 1u);
+        return false;
+    }
+    b.cos_lo = __builtin_amdgcn_sqrtf(1.0f - b.sin_hi * b.sin_hi) * 0.999999f;
+    uint32_t* const ww = lane_words - lane;
+    uint32_t* const cand = hl.wq;
+    uint32_t n_cand = 0u;
+    const uint4 q2 = S.all_q2, q3 = S.all_q3;
+    if (q2.y >= CULL_MIN_SPHERES && !beam_collect<0>(S, b, q2.x, q2.y, q3.z, ww, stride, cand, n_cand, lane)) return false;
+    if (q3.w != 0xffffffffu && !beam_collect<1>(S, b, q3.x, q3.y, q3.w, ww, stride, cand, n_cand, lane)) return false;
+    if (S.all_w != 0xffffffffu) {
+        const uint32_t cyl_n = __float_as_uint(ld_f4<true>(S.bnd, S.all_w).w) >> 3;
+        if (!beam_collect<2>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, cand, n_cand, lane)) return false;
+    }
+    if (n_cand > most) {  // (the caller has a cheaper way for so many)
+        if (lane == 0u) RT_HITSTAT(8, 1u);
+        return false;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0u) {
+        RT_HITSTAT(6, 1u);
+        RT_HITSTAT(10, n_cand);
+    }
+    // ---- every candidate to every ray: 64 at a time into registers (each lane fetches one), then handed round
+    for (uint32_t c0 = 0u; c0 < n_cand; c0 += 64u) {
+        const uint32_t n = n_cand - c0 < 64u ? n_cand - c0 : 64u;
+        const uint32_t my_e = cand[c0 + (lane < n ? lane : 0u)];
+        const uint32_t my_i = my_e & 0x3fffffffu;
+        const float4 my_rec = (my_e >> 30) == 0u ? S.sph[my_i] : ((my_e >> 30) == 1u ? S.poly_bound[my_i] : S.cone_bound[my_i]);
+        for (uint32_t j = 0u; j < n; ++j) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
+            const float4 rec = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.x), (int)j)),
+                                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.y), (int)j)),
+                                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.z), (int)j)),
+                                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.w), (int)j)));
+            const uint32_t kind = e >> 30, i = e & 0x3fffffffu;
+            if (kind == 0u) {
+                float d, c;
+                if (live && sphere_quick(rec.x, rec.y, rec.z, rec.w, src, ray, a, d, c)) sphere_finish<true>(S, i, d, c, a, near, ignore, hl, ctr);
+            } else if (kind == 1u) {
+                if (live && bound_may_hit<BEHIND>(rec, src, un)) polygon_item<true, true>(S, i, src, ray, near, ignore, hl, ctr);
+            } else {
+                if (live && bound_may_hit<BEHIND>(rec, src, un)) cone_item<true>(S, i, src, ray, near, ignore, hl, ctr);
+            }
+        }
+    }
+    return true;
+}
+
 // MODE: 1 / 2 as CULL's low bits.  SHADOW: only "is the walk's hit at most `limit` away" is wanted (out.dist is
 // the walk's distance when it returns true; no normal is formed).
-template <int MODE, bool SHADOW, class Ctr>
+// BEAM: step (A) by beam_runs where it can be; 1: the rays of a wave leave one point (camera rays), 2: they make for one
+// point, `apex` (shadow rays); 3: as 1, for trees that partition well: only with at most RT_BEAM_MOST candidates, and a
+// wave it is not done for is walked leaf by leaf (KdWalk), which there costs less than finding all of a ray's hits.
+template <int MODE, bool SHADOW, class Ctr, int BEAM = 0>
 RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out, uint2* stack,
-                             Ctr& ctr, float limit) {
+                             Ctr& ctr, float limit, F3 apex = F3{0.0f, 0.0f, 0.0f}) {
     static_assert(MODE == 1 || MODE == 2, "the hit-list walk goes by the bounding records");
     const uint32_t stride = blockDim.x;
     uint2* const ring = stack + threadIdx.x;
@@ -1159,12 +1388,23 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     hl.init(ring, (uint32_t*)(stack + (uint32_t)RT_STACK_RING * stride) + (uint32_t)RT_LANE_WORDS * stride + (threadIdx.x >> 6) * WQ_CAP, stride);
     RT_PHASE_T0();
     RT_HITSTAT(0, 1u);
+    bool beamed = false;
+    if constexpr (BEAM != 0)
+        beamed = beam_runs<BEAM == 2, MODE == 2>(S, src, ray, unit_ray(ray, tame ? a : 1.0f), a, near, ignore, tame, tame && in_root, hl, ctr,
+                                                 lane_words, stride, apex, limit, BEAM == 3 ? (uint32_t)RT_BEAM_MOST : WQ_CAP);
+    if constexpr (BEAM == 3) {
+        if (!beamed) return in_root && kd_traverse_closest<MODE, Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
+    }
     if (tame && in_root) {  // ---- (A)  the walk of a leaf (KdWalk::round), of the leaf that lists every primitive
         constexpr bool BEHIND = MODE == 2;
         const F3 un = unit_ray(ray, a);
         NoOccluder occ;
         const lds_cf4_ptr no_lrec = (lds_cf4_ptr) nullptr;
         uint4 q2 = S.all_q2, q3 = S.all_q3;  // (the same for every lane: scalar registers)
+        if (beamed) {  // (the three runs with bounding records are done)
+            if (q2.y >= CULL_MIN_SPHERES) q2.y = 0u;
+            if (q3.w != 0xffffffffu) q3.y = 0u;
+        } else {
         if (q2.y >= CULL_MIN_SPHERES) {  // spheres, through their bounding records
             leaf_run_lane<0, BEHIND, false>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
             q2.y = 0u;
@@ -1180,6 +1420,7 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
             const uint32_t cyl_n = __float_as_uint(S.bnd[S.all_w].w) >> 3;
             leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
             hl.template flush<2>(S, src, ray, near, ignore, ctr);
+        }
         }
         RT_PHASE(3);
         // cones proper, which no record bounds: every lane tests every one (entries by scalar loads when they are many)
@@ -1311,7 +1552,7 @@ template <int CULL, class Ctr, int OCC>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr, float limit) {
     if constexpr ((CULL & 64) != 0) {  // (+ 64: the hit-list walk)
-        return kd_traverse_hits<CULL & 3, false>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        return kd_traverse_hits<CULL & 3, false, Ctr, (CULL & 128) == 0 ? 0 : ((CULL & 256) != 0 ? 3 : 1)>(S, src, ray, near, ignore, out, stack, ctr, limit);
     } else {
         KdDeep<(CULL & 4) == 0> deep;
         KdWalk<CULL, Ctr, OCC> w(S, stack, ctr, deep);

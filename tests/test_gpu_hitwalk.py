@@ -2,7 +2,7 @@
 sub-trees that hold a hit primitive -- rust-raytracer_amd/csrc/rt_traverse.h) on the cases that are its own: that it
 is what runs on scenes with cones or many polygons, rays with more hits than a lane keeps (handed to the
 leaf-by-leaf walk), waves with more cone and polygon candidates than their queue holds, rays the bounding records
-cannot take.  Every frame and every ray must equal the CPU oracle's bit for bit, as everywhere else."""
+cannot take, camera rays taken a tile at a time (the beam of beam_runs).  Every frame and every ray must equal the CPU oracle's bit for bit, as everywhere else."""
 import numpy as np
 import pytest
 
@@ -20,7 +20,7 @@ def frames_equal_oracle(rtamd, oracle, ctx, text, depth, width, height, expect_h
     o = oracle.OracleScene(text)
     of, ou, octr, _ = o.render(width, height, max_depth=depth, pow_mode=oracle.POW_PORTABLE, threads=8)
     out = {}
-    for leaf_walk in (False, True):
+    for leaf_walk in (False, True, 2):  # (2: camera rays by the tile's beam, without the timing that decides on it)
         f, u, st = sc.render(rtamd.RenderOptions(max_depth=depth, leaf_walk=leaf_walk), width, height)
         assert np.array_equal(bits(f), bits(of)) and np.array_equal(u, ou), leaf_walk
         for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
@@ -29,6 +29,7 @@ def frames_equal_oracle(rtamd, oracle, ctx, text, depth, width, height, expect_h
     if expect_hit_walk:
         assert out[False].kernel_shadow >= 0 and (out[False].kernel_shadow & 64) != 0, out[False].kernel_shadow
         assert out[False].kernel_deep < 0 or (out[False].kernel_deep & 64) != 0
+        assert out[2].kernel_shadow >= 0 and (out[2].kernel_shadow & 64) != 0
     assert out[True].kernel_shadow < 0 or (out[True].kernel_shadow & 64) == 0
     return sc, o
 
@@ -123,3 +124,42 @@ def test_rays_the_bounding_records_cannot_take(rtamd, oracle, spd, gpu_ctx):
     for flags in (0, rtamd.DEBUG_LEAF_WALK):
         gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | flags)
         assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn)), flags
+
+
+@pytest.mark.parametrize("case", ("lathe", "rings", "wide", "ragged", "inside", "near"))
+def test_camera_rays_a_tile_at_a_time(rtamd, oracle, spd, gpu_ctx, case):
+    """The 64 camera rays of a tile leave one point; the records none of them can pass are ruled out once for all of
+    them (a cone about the tile's rays), the entries left are taken to every ray.  Views that strain the cone: a
+    field of view of 150 degrees (no cone is formed about rays that spread that wide), image sizes that leave
+    tiles with fewer than 64 rays, an eye inside the bounding spheres of most of the scene, an eye that almost
+    touches a primitive.  Default options time the first two frames of a kind, one each way, and keep the faster:
+    whichever runs, the frame is the oracle's."""
+    w, h, depth = 160, 120, 4
+    if case == "lathe":
+        text = spd.lathe(nu=32, nv=16, width=w, height=h)
+    else:
+        text = spd.rings(2, w, h)
+    if case == "wide":
+        text = text.replace("angle 25", "angle 150") if "angle 25" in text else "\n".join(
+            ("angle 150" if l.startswith("angle") else l) for l in text.split("\n"))
+    if case == "ragged":
+        w, h = 157, 83
+    if case in ("inside", "near"):
+        lines = text.split("\n")
+        for k, l in enumerate(lines):
+            if l.startswith("from"):
+                lines[k] = "from 0.3 0.2 0.4" if case == "inside" else "from 1.02 0.9 0.35"
+            if l.startswith("hither"):
+                lines[k] = "hither 0.001"
+        text = "\n".join(lines)
+    try:
+        o = oracle.OracleScene(text)
+    except Exception as e:
+        pytest.skip(str(e))
+    sc = rtamd.Scene.from_nff(gpu_ctx, text)
+    of, ou, octr, _ = o.render(w, h, max_depth=depth, pow_mode=oracle.POW_PORTABLE, threads=8)
+    for leaf_walk in (2, 0, 0, 0, 0, 1):
+        f, u, st = sc.render(rtamd.RenderOptions(max_depth=depth, leaf_walk=leaf_walk), w, h)
+        assert np.array_equal(bits(f), bits(of)) and np.array_equal(u, ou), leaf_walk
+        for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
+            assert st.as_dict()[k] == octr[k], (leaf_walk, k)

@@ -62,13 +62,14 @@ def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, heig
     # out) and the exhaustive leaf walk must both give the same bits and the same rays
     # (and of the default kernels both walks: all of a ray's hits first, then the sub-trees that hold one -- what
     # scenes with cones or many polygons get --, and leaf by leaf)
-    for exhaustive, leaf_walk in ((False, False), (False, True), (True, False)):
+    # (leaf_walk 2: camera rays by the tile's beam where the scene has the tables for it)
+    for exhaustive, leaf_walk in ((False, 0), (False, 1), (False, 2), (True, 0)):
         cf, cu, cst = sc.render(rtamd.RenderOptions(max_depth=depth, fp_mode=rtamd.FP_EXACT,
                                                     exhaustive_leaves=exhaustive, leaf_walk=leaf_walk), width, height)
         assert np.array_equal(bits(cf), bits(of_p)) and np.array_equal(cu, ou_p), (exhaustive, leaf_walk)
         for k in RAY_KEYS:
             assert cst.as_dict()[k] == octr[k], (exhaustive, leaf_walk, k)
-        if leaf_walk or exhaustive:  # (kernel ids: + 64 = the hit-list walk; -1 = no such launch)
+        if leaf_walk == 1 or exhaustive:  # (kernel ids: + 64 = the hit-list walk; -1 = no such launch)
             assert all(k < 0 or (k & 64) == 0 for k in (cst.kernel_shadow, cst.kernel_deep))
     # exact mode vs libm powf (the reference's pow)
     any_diff, big_diff, _ = lsb_report(gu, ou_l)

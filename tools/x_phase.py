@@ -22,7 +22,7 @@ for _ in range(2):
     st = sc.render_device(opt, None, out.data_ptr(), None, w, h)
 buf = (C.c_ulonglong * 8)()
 L.rt_x_phase_cycles(buf, 1)
-hs = (C.c_ulonglong * 8)()
+hs = (C.c_ulonglong * 16)()
 L.rt_x_hit_stats(hs, 1)
 st = sc.render_device(opt, None, out.data_ptr(), None, w, h)
 L.rt_x_phase_cycles(buf, 1)
@@ -37,4 +37,7 @@ h = list(hs)
 if h[0]:
     print("   hit-list walk: rays %d, walked leaf by leaf %.4f %%, hits per ray %.2f, in step (B) %.1f %%, its interior steps per such ray %.1f, leaves %.2f"
           % (h[0], 100.0 * h[1] / h[0], h[2] / h[0], 100.0 * h[3] / h[0], h[4] / max(1, h[3]), h[5] / max(1, h[3])))
+    if h[6] + h[7] + h[8] + h[9]:
+        print("   beam: waves done %d (candidates per wave %.1f, records tested per wave %.1f), not tried %d, candidates outgrew %d, pending outgrew %d"
+              % (h[6], h[10] / max(1, h[6]), h[11] / max(1, h[6] + h[8] + h[9]), h[7], h[8], h[9]))
     print("   (phases of the hit-list walk: 0 = step (B), 1 spheres, 2 polygons, 3 cylinders, 4 cones and short runs, 5 the answer's normal)")
