@@ -609,8 +609,10 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     uint4 all_rec[3] = {make_uint4(0xffffffffu, 3u, 0u, 0u), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0xffffffffu)};
     std::vector<float4> pboxes;
     std::vector<uint32_t> prim_entry;
-    bool hit_walk = !lean_scene && sd.primitives.size() > 0 && sd.primitives.size() < (1u << 29) &&
-                    sc->tree.nodes.size() < (1u << HITWALK_NODE_BITS);
+    // (Lean scenes get the tables too: their camera rays may go a tile at a time, choose_level0; every other ray of
+    // theirs keeps the lean kernels, which never see the extra leaf's records.)
+    bool hit_walk = sd.primitives.size() > 0 && sd.primitives.size() < (1u << 29) && sc->tree.nodes.size() < (1u << HITWALK_NODE_BITS);
+    const size_t bnd_real = bnd.size();  // the real leaves' bounding records end here
     bool force_hit_walk = false;  // (experiment, RTAMD_HIT_WALK=2: also scenes of spheres alone, which then run the general kernels)
     if (const char* e = getenv("RTAMD_HIT_WALK")) {
         hit_walk = hit_walk && atoi(e) != 0;
@@ -742,13 +744,14 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.n_lights = (uint32_t)sd.lights.size();
     d.stack_depth = std::max<uint32_t>(1, sc->tree.info.max_depth);
     // lean: no cones and next to no polygons (a floor): kernels without the code for either's records
-    d.bnd_records = (uint32_t)(bnd.size() / 4);
+    d.bnd_records = (uint32_t)(bnd_real / 4) + 8u;  // (what a lean kernel's blocks copy: the real leaves' records, read eight at a time)
     d.lean = (lean_scene && !force_hit_walk && d.stack_depth <= RT_STACK_RING &&
-              bnd.size() * sizeof(float) <= RT_LEAN_RECORD_BYTES) ? 1u : 0u;
+              (size_t)d.bnd_records * sizeof(float4) <= RT_LEAN_RECORD_BYTES) ? 1u : 0u;
     d.n_nodes = (uint32_t)sc->tree.nodes.size();
-    d.hit_walk = hit_walk ? 1u : 0u;
-    d.hit_walk_level0 = (hit_walk && (uint64_t)sc->tree.info.max_leaf * 4u >= sd.primitives.size()) ? 1u : 0u;
-    if (const char* e = getenv("RTAMD_HIT_LEVEL0")) d.hit_walk_level0 = (hit_walk && atoi(e) != 0) ? 1u : 0u;  // (experiment)
+    d.hit_tables = hit_walk ? 1u : 0u;
+    d.hit_walk = (hit_walk && d.lean == 0u) ? 1u : 0u;
+    d.hit_walk_level0 = (d.hit_walk != 0u && (uint64_t)sc->tree.info.max_leaf * 4u >= sd.primitives.size()) ? 1u : 0u;
+    if (const char* e = getenv("RTAMD_HIT_LEVEL0")) d.hit_walk_level0 = (d.hit_walk != 0u && atoi(e) != 0) ? 1u : 0u;  // (experiment)
     d.prim_box = sc->prim_box.p;
     d.prim_entry = sc->prim_entry.p;
     d.all_w = all_rec[0].x;
@@ -841,8 +844,7 @@ void choose_level0(rt_context* ctx, FrameSlot& f, const FramePlan& p) {
     f.l0_trial = false;
     const DevScene& d = f.scene->dev;
     const rt_options& o = f.opt;
-    if (ctx->beam_level0 == 0 || o.collect_work != 0 || o.exhaustive_leaves != 0 || o.leaf_walk == 1u || d.lean != 0u || d.hit_walk == 0u ||
-        d.hit_walk_level0 != 0u)
+    if (ctx->beam_level0 == 0 || o.collect_work != 0 || o.exhaustive_leaves != 0 || o.leaf_walk == 1u || d.hit_tables == 0u || d.hit_walk_level0 != 0u)
         return;
     if (ctx->beam_level0 >= 2 || o.leaf_walk == 2u) {
         f.l0_variant = 1;
@@ -904,7 +906,7 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     memset(&A, 0, sizeof(A));
     A.scene = scene->dev;
     if (opt->leaf_walk == 1u) A.scene.hit_walk = 0u;
-    if (A.scene.hit_walk != 0u && A.scene.hit_walk_level0 == 0u && f.l0_variant == 1) A.scene.hit_walk_level0 = 2u;  // (2: the beam, or leaf by leaf)
+    if (A.scene.hit_tables != 0u && A.scene.hit_walk_level0 == 0u && f.l0_variant == 1) A.scene.hit_walk_level0 = 2u;  // (2: the beam, or leaf by leaf)
     const Camera cam = camera_basis(*view);
     memcpy(A.from, view->from, 12);
     memcpy(A.fwd, cam.forward, 12);
@@ -1310,13 +1312,14 @@ int begin_frame(rt_context* ctx, const rt_scene* scene, const rt_view* view, con
     // that size, or to come close.
     choose_level0(ctx, f, p);
     // (a frame whose camera rays are timed runs alone: it is waited for like one of unproven size)
-    const bool proven = ctx->hint_scene == scene->serial && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth && !f.l0_trial;
+    const bool known = ctx->hint_scene == scene->serial && ctx->hint_slots == p.n_slots && ctx->hint_depth == opt->max_depth;
+    const bool proven = known && !f.l0_trial;
     const size_t floor_cap = std::max<size_t>((size_t)p.n_slots * 2, 1u << 16);
     // (The wanted sizes carry a quarter of headroom and creep up with every frame that needs a little more than
     // any before -- a camera going round a scene.  A slot that holds all but an eighth of them keeps its pools:
     // growing them means freeing them, which waits for everything in flight on the device.  lathe 96 at 1920x1080,
     // twenty views round the scene with four frames in flight: 3.6 -> 1.8 ms per frame.)
-    auto wanted = [&](size_t have, size_t want) { return proven && have < want - want / 8 ? want : have; };
+    auto wanted = [&](size_t have, size_t want) { return known && have < want - want / 8 ? want : have; };
     const size_t cap = std::max(wanted(f.ws.pool_cap, ctx->want_pool), floor_cap);
     const size_t scap = std::max(wanted(f.ws.shadow_cap / p.lights1, ctx->want_shadow1), floor_cap);
     // Any other frame is waited for here, pools grown and the frame re-run as often as it takes, so that

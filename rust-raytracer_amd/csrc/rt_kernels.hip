@@ -1256,13 +1256,13 @@ hipError_t init_kernels() {
 hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool cull, uint32_t grid, hipStream_t st, int* variant) {
     const bool lean = A.scene.lean != 0;
     const uint32_t which = level == 0 ? 0u : 1u;
-    const bool beam_or_leaf = RT_BEAM != 0 && !work && cull && !lean && level == 0 && A.scene.hit_walk != 0u && A.scene.hit_walk_level0 == 2u;
-    const bool hit_walk = cull && !lean && A.scene.hit_walk != 0u && (level > 0 || beam_or_leaf || (RT_HITS_LEVEL0 != 0 && A.scene.hit_walk_level0 == 1u));
+    const bool beam_or_leaf = RT_BEAM != 0 && !work && cull && level == 0 && A.scene.hit_tables != 0u && A.scene.hit_walk_level0 == 2u;
+    const bool hit_walk = beam_or_leaf || (cull && !lean && A.scene.hit_walk != 0u && (level > 0 || (RT_HITS_LEVEL0 != 0 && A.scene.hit_walk_level0 == 1u)));
     const bool gen_stays = !work && cull && !lean && !hit_walk && A.scene.nodes_lds != 0u && level > 0 && RT_STAY_GEN_DEEP != 0;
     const bool stays = gen_stays || (!work && cull && lean && g_lean_stays[which]);
     const uint32_t tb = trace_block(A.scene, stays, which);
     const dim3 g(blocks_of(grid, tb, stays, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU)), b(tb);
-    const size_t lds = stack_bytes(A.scene, !work && cull && lean, tb, stays, hit_walk);
+    const size_t lds = stack_bytes(A.scene, !work && cull && lean && !beam_or_leaf, tb, stays, hit_walk);
     if (variant) {
         if (level == 0) *variant = !cull ? 0 : (beam_or_leaf ? HITS_I0L : (hit_walk ? HITS_I0 : (!work && lean ? LEAN_I0 : 1)));
         else *variant = !cull ? 0 : (hit_walk ? HITS_ID : (work ? 2 : (lean ? LEAN_ID : (gen_stays ? GEN_ID : 2))));

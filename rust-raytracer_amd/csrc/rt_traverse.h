@@ -1200,9 +1200,9 @@ RT_DEV uint32_t below_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_
 
 // The candidate entries of one run (KIND as leaf_run_lane's), appended to cand[0 .. n_cand) as KIND << 30 | entry.
 // ww: the wave's lane words (word j at ww[(j >> 6) * stride + (j & 63)]).  All 64 lanes; false: no room.
-template <int KIND>
+template <int KIND, class Ctr>
 RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint32_t count, uint32_t header, uint32_t* ww,
-                         uint32_t stride, uint32_t* cand, uint32_t& n_cand, uint32_t lane) {
+                         uint32_t stride, uint32_t* cand, uint32_t& n_cand, uint32_t lane, Ctr& ctr) {
     const float4 hf = ld_f4<true>(S.bnd, header), whole = ld_f4<true>(S.bnd, header + 1u);
     if (!b.may_hit(whole.x, whole.y, whole.z, whole.w)) return true;
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
@@ -1233,6 +1233,8 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
             }
         }
         const bool pass = mine && b.may_hit(rec.x, rec.y, rec.z, rec.w);
+        if (mine) ctr.bound_tests(1);
+        if (lane == 0u) ctr.lane_slots(64);
         const uint64_t m_entry = __ballot(pass && L == 0u), m_inner = __ballot(pass && L != 0u);
         const uint32_t n_entry = (uint32_t)__popcll(m_entry), n_inner = (uint32_t)__popcll(m_inner);
         if (lane == 0u) RT_HITSTAT(11, n);
@@ -1321,11 +1323,11 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
     uint32_t* const cand = hl.wq;
     uint32_t n_cand = 0u;
     const uint4 q2 = S.all_q2, q3 = S.all_q3;
-    if (q2.y >= CULL_MIN_SPHERES && !beam_collect<0>(S, b, q2.x, q2.y, q3.z, ww, stride, cand, n_cand, lane)) return false;
-    if (q3.w != 0xffffffffu && !beam_collect<1>(S, b, q3.x, q3.y, q3.w, ww, stride, cand, n_cand, lane)) return false;
+    if (q2.y >= CULL_MIN_SPHERES && !beam_collect<0>(S, b, q2.x, q2.y, q3.z, ww, stride, cand, n_cand, lane, ctr)) return false;
+    if (q3.w != 0xffffffffu && !beam_collect<1>(S, b, q3.x, q3.y, q3.w, ww, stride, cand, n_cand, lane, ctr)) return false;
     if (S.all_w != 0xffffffffu) {
         const uint32_t cyl_n = __float_as_uint(ld_f4<true>(S.bnd, S.all_w).w) >> 3;
-        if (!beam_collect<2>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, cand, n_cand, lane)) return false;
+        if (!beam_collect<2>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, cand, n_cand, lane, ctr)) return false;
     }
     if (n_cand > most) {  // (the caller has a cheaper way for so many)
         if (lane == 0u) RT_HITSTAT(8, 1u);
@@ -1349,6 +1351,15 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
                                            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.z), (int)j)),
                                            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.w), (int)j)));
             const uint32_t kind = e >> 30, i = e & 0x3fffffffu;
+            if (lane == 0u) ctr.lane_slots(64);
+            if constexpr (Ctr::kEnabled) {
+                if (kind == 0u) {
+                    const uint2 id = ld_u2<true>(S.sph_id, i);
+                    if (live && id.x != ignore && (id.y >> 31) == 0u) ctr.sphere_tests(1);  // (as the other walks count them)
+                } else if (live) {
+                    ctr.bound_tests(1);
+                }
+            }
             if (kind == 0u) {
                 float d, c;
                 if (live && sphere_quick(rec.x, rec.y, rec.z, rec.w, src, ray, a, d, c)) sphere_finish<true>(S, i, d, c, a, near, ignore, hl, ctr);
