@@ -374,6 +374,12 @@ int rt_debug_eval(rt_context* ctx, uint32_t op, uint32_t fp_mode, uint64_t n, co
  * Returns 1 and fills out4, or 0 when the primitive has no such sphere. */
 int rt_debug_bound(uint32_t kind, const rt_cone* cone, const rt_vertex* verts, uint32_t n_verts, float* out4);
 
+/* Diagnostic, host only (no reference counterpart): the axis-aligned box {lo xyz, hi xyz} that stands in for the
+ * polygon `verts[0 .. n_verts)` in the bounding records of polygon runs.  Whenever the reference's test of the
+ * polygon accepts a ray, the accepted point lies inside the box widened on every side by 1.1e-5 |src - centre|,
+ * centre = the box's.  Returns 1 and fills out6, or 0 when the polygon has no such box. */
+int rt_debug_polygon_box(const rt_vertex* verts, uint32_t n_verts, float* out6);
+
 #ifdef __cplusplus
 }
 #endif

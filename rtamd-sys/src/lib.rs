@@ -291,4 +291,5 @@ extern "C" {
     pub fn rt_debug_eval(ctx: *mut rt_context, op: u32, fp_mode: u32, n: u64, input: *const f32, in_stride: u32,
                          out: *mut f32, out_stride: u32, verts: *const rt_vertex, n_verts: u32) -> c_int;
     pub fn rt_debug_bound(kind: u32, cone: *const rt_cone, verts: *const rt_vertex, n_verts: u32, out4: *mut f32) -> c_int;
+    pub fn rt_debug_polygon_box(verts: *const rt_vertex, n_verts: u32, out6: *mut f32) -> c_int;
 }

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = (
     "rt_tile_pixels_max", "rt_tile_slot", "rt_deinterleave_device", "rt_deinterleave_host", "rt_nff_parse",
     "rt_parsed_desc", "rt_parsed_view", "rt_parsed_warning_count", "rt_parsed_free", "rt_ppm_write",
     "rt_tree_build", "rt_tree_get", "rt_tree_free", "rt_camera_basis", "rt_debug_intersect", "rt_debug_eval",
-    "rt_debug_bound", "rt_frames_in_flight", "rt_context_set_workspace_limit", "rt_render_device_static", "rt_context_device_count",
+    "rt_debug_bound", "rt_debug_polygon_box", "rt_frames_in_flight", "rt_context_set_workspace_limit", "rt_render_device_static", "rt_context_device_count",
     "rt_context_peer_access",
 )
 
@@ -212,6 +212,8 @@ def lib():
     L.rt_camera_basis.restype = None
     L.rt_debug_bound.argtypes = [C.c_uint32, vp, vp, C.c_uint32, vp]
     L.rt_debug_bound.restype = C.c_int
+    L.rt_debug_polygon_box.argtypes = [vp, C.c_uint32, vp]
+    L.rt_debug_polygon_box.restype = C.c_int
     L.rt_frames_in_flight.argtypes = [vp]
     L.rt_frames_in_flight.restype = C.c_uint32
     L.rt_context_set_workspace_limit.argtypes = [vp, C.c_uint64]
@@ -556,6 +558,15 @@ def debug_bound(kind, cone8=None, verts6=None):
     verts = np.ascontiguousarray(verts6, dtype=np.float32) if verts6 is not None else None
     ok = lib().rt_debug_bound(kind, _ptr(cone) if cone is not None else None, _ptr(verts) if verts is not None else None,
                               0 if verts is None else verts.shape[0], _ptr(out))
+    return out if ok else None
+
+
+def debug_polygon_box(verts6):
+    """The box (lo xyz, hi xyz) standing in for one polygon in the box records of polygon runs
+    (rt_debug_polygon_box), or None.  verts6: [n, 6] points and normals."""
+    out = np.zeros(6, dtype=np.float32)
+    verts = np.ascontiguousarray(verts6, dtype=np.float32)
+    ok = lib().rt_debug_polygon_box(_ptr(verts), verts.shape[0], _ptr(out))
     return out if ok else None
 
 

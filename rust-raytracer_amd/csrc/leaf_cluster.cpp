@@ -4,7 +4,7 @@
 // tree degenerates into leaves of thousands of spheres that walk is the whole cost.  The
 // device may skip a group of spheres when it can PROVE that the reference's test would reject
 // each of them for this ray.  The (spatially re-ordered) sphere run is grouped 8 entries to a
-// level-1 record, 8 level-1 records to a level-2 record, and so on up to level 4; every record
+// level-1 record, 8 level-1 records to a level-2 record, and so on up to level 5; every record
 // is a bounding sphere {centre C, q} of all entries below it.  Re-ordering is free: list
 // order only matters for ties, and every entry keeps its list position for that.
 //
@@ -41,6 +41,12 @@ float round_up(double x) {
     float f = (float)x;
     if ((double)f < x) f = std::nextafter(f, INFINITY);
     return std::nextafter(f, INFINITY);
+}
+
+float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafter(f, -INFINITY);
+    return std::nextafter(f, -INFINITY);
 }
 
 // Radius of the smallest sphere about `c` that holds entries [b, e) of v.
@@ -191,7 +197,7 @@ void arrange(std::vector<LeafSphere>& v) {
 // decided here in binary64 with the worst f32 deviation of either kernel build (plain or fused
 // multiply-add) as a dead band; inside the band every axis is allowed for.
 // ---------------------------------------------------------------------------------------
-bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, float c_out[3], float* r_out) {
+bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, float c_out[3], float* r_out, float* box6) {
     const double u = 5.9604644775390625e-8;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t i = 0; i < count; ++i)
@@ -249,6 +255,16 @@ bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, fl
     R = std::sqrt(R);
     const double Rp = R * (1.0 + 2e-5) + 2e-5 * std::sqrt(cn);
     *r_out = round_up(Rp);
+    if (box6) {
+        // The same box, as a box: the widening of 32u (M + |src| + |X - src| + |v0 - src|) is at most
+        // 1.9e-6 (3 R + 2 |C| + 3 |src - C|) + ..., of which 2e-5 (R + |C|) goes into the box here and
+        // 1.1e-5 |src - C| is left to the ray (the shares the sphere above takes).
+        const double s = 2e-5 * (R + std::sqrt(cn));
+        for (int a = 0; a < 3; ++a) {
+            box6[a] = round_down(blo[a] - s);
+            box6[3 + a] = round_up(bhi[a] + s);
+        }
+    }
     return Rp == Rp && *r_out < 1e30f;
 }
 
@@ -325,11 +341,12 @@ void sphere_record(const LeafSphere& e, float out[4]) {
 //   [h]            header, as integers: {first level-2 record, first level-3, first level-4,
 //                  top level | padded entry count << 3}
 //   [h+1]          one record bounding the whole run
-//   [h+2 ...]      level-1 records (one per 8 entries), then levels 2, 3, 4.
+//   [h+2 ...]      level-1 records (one per 8 entries), then levels 2, 3, 4, 5, one after the other
+//                  (level 5 starts where level 4 ends: the header has no word for it).
 // Record i of level L bounds records 8i .. 8i+7 of level L-1 (entries 8i .. 8i+7 for L = 1).
-// The top level is the lowest one with at most 16 records (level 4 if none is that small); the
+// The top level is the lowest one with at most 16 records (level `max_level`, 4 or 5, if none is that small); the
 // device tests it linearly and descends from there.
-uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd) {
+uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd, int max_level) {
     const uint32_t h = (uint32_t)(bnd.size() / 4);
     if (v.empty()) return h;
     arrange(v);
@@ -340,10 +357,10 @@ uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd) {
         bound(v, 0, n, rec);
         bnd.insert(bnd.end(), rec, rec + 4);
     }
-    uint32_t first[5] = {0, h + 2, 0, 0, 0};
-    size_t count[5] = {0, 0, 0, 0, 0};
+    uint32_t first[6] = {0, h + 2, 0, 0, 0, 0};
+    size_t count[6] = {0, 0, 0, 0, 0, 0};
     size_t span = 8;  // entries per record of the level
-    for (int L = 1; L <= 4; ++L, span *= 8) {
+    for (int L = 1; L <= 5; ++L, span *= 8) {
         first[L] = (uint32_t)(bnd.size() / 4);
         count[L] = (n + span - 1) / span;
         for (size_t i = 0; i < count[L]; ++i) {
@@ -352,12 +369,49 @@ uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd) {
             bnd.insert(bnd.end(), rec, rec + 4);
         }
     }
-    uint32_t top = 4;
-    for (int L = 4; L >= 1; --L)
+    uint32_t top = (uint32_t)max_level;
+    for (int L = max_level; L >= 1; --L)
         if (count[L] <= 16) top = (uint32_t)L;
     const uint32_t hdr[4] = {first[2], first[3], first[4], top | ((uint32_t)n << 3)};
     memcpy(&bnd[(size_t)h * 4], hdr, sizeof(hdr));
     return h;
+}
+
+void cluster_boxes(const std::vector<LeafSphere>& v, const std::vector<float>& bnd, uint32_t h, std::vector<float>& box) {
+    const size_t records = bnd.size() / 4;
+    const size_t had = box.size() / 8;
+    box.resize(records * 8);
+    for (size_t i = had; i < records; ++i) {
+        float* b = &box[i * 8];
+        b[0] = b[1] = b[2] = -INFINITY;
+        b[4] = b[5] = b[6] = INFINITY;
+        b[3] = b[7] = 0.0f;
+    }
+    const size_t n = v.size();
+    if (n == 0 || (size_t)h + 2 > records) return;
+    uint32_t hdr[4];
+    memcpy(hdr, &bnd[(size_t)h * 4], sizeof(hdr));
+    uint32_t first[6] = {0, h + 2, hdr[0], hdr[1], hdr[2], 0};
+    first[5] = first[4] + (uint32_t)((n + 4095) / 4096);
+    auto unite = [&](size_t rec, size_t b, size_t e) {
+        float* o = &box[rec * 8];
+        for (int a = 0; a < 3; ++a) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (size_t i = b; i < e; ++i) {
+                lo = std::min(lo, v[i].lo[a]);  // (min and max of f32 values: exact)
+                hi = std::max(hi, v[i].hi[a]);
+                if (!(v[i].lo[a] == v[i].lo[a]) || !(v[i].hi[a] == v[i].hi[a])) { lo = -INFINITY; hi = INFINITY; break; }
+            }
+            o[a] = lo;
+            o[4 + a] = hi;
+        }
+    };
+    unite((size_t)h + 1, 0, n);
+    size_t span = 8;
+    for (int L = 1; L <= 5; ++L, span *= 8) {
+        const size_t count = (n + span - 1) / span;
+        for (size_t i = 0; i < count; ++i) unite((size_t)first[L] + i, i * span, std::min(n, (i + 1) * span));
+    }
 }
 
 }  // namespace rtamd

@@ -194,7 +194,8 @@ struct rt_scene {
     DevBuf<uint4> nodes, cone_items, poly_items;
     DevBuf<float4> sph;
     DevBuf<uint2> sph_id;
-    DevBuf<float> bnd;
+    DevBuf<float> bnd, bnd_box;
+    DevBuf<float4> poly_box;
     DevBuf<float4> cones, poly_rec, poly_bound, cone_bound, vpos, vnrm, surfaces, lights;
     DevBuf<uint32_t> prim_surface, prim_entry;
     DevBuf<float4> prim_box;
@@ -513,6 +514,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     std::vector<float4> sph;
     std::vector<uint2> sph_id;
     std::vector<float> bnd;  // 4 floats per record
+    std::vector<float> bnd_box;  // 8 floats per record of bnd: the box records of polygon runs (cluster_boxes)
+    std::vector<float4> poly_box;  // 2 per polygon item: its own box {lo, -} {hi, -}
     std::vector<uint4> cone_items, poly_items;
     std::vector<float4> cone_bound, poly_bound;  // one record per item, for the item alone
     auto push_record = [](std::vector<float4>& to, const LeafSphere& e) {
@@ -540,10 +543,14 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
             } else {
                 const rt_polygon& pg = sd.polygons[p.index];
                 LeafSphere e{{0.0f, 0.0f, 0.0f}, 0.0f, prim, k, pg.first_vertex, pg.vertex_count};
-                if (!polygon_bound(sd.vertices.data(), pg.first_vertex, pg.vertex_count, e.c, &e.r)) {
+                float box6[6];
+                if (!polygon_bound(sd.vertices.data(), pg.first_vertex, pg.vertex_count, e.c, &e.r, box6)) {
                     poly_bounds = false;
                     e.c[0] = e.c[1] = e.c[2] = 0.0f;
                     e.r = INFINITY;
+                } else {
+                    memcpy(e.lo, box6, 12);
+                    memcpy(e.hi, box6 + 3, 12);
                 }
                 lp.push_back(e);
             }
@@ -551,12 +558,15 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
         // polygon runs worth a hierarchy get one over the spheres that stand in for the polygons
         uint32_t pu0 = 0xffffffffu;
         if (poly_bounds && lp.size() >= RT_HIER_MIN) {
-            pu0 = cluster_spheres(lp, bnd);
+            pu0 = cluster_spheres(lp, bnd, 5);
+            cluster_boxes(lp, bnd, pu0, bnd_box);
             any_poly_walk = true;
         }
         for (const LeafSphere& e : lp) {
             poly_items.push_back(make_uint4(e.prim, e.pos, e.a0, e.a1));
             push_record(poly_bound, e);
+            poly_box.push_back(make_float4(e.lo[0], e.lo[1], e.lo[2], 0.0f));
+            poly_box.push_back(make_float4(e.hi[0], e.hi[1], e.hi[2], 0.0f));
         }
         // Cone items: the cylinders first (under a hierarchy of their own when there are enough of
         // them), then the cones proper, which no sphere can stand in for.
@@ -704,6 +714,13 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     cone_bound.insert(cone_bound.end(), 8, make_float4(0.0f, 0.0f, 0.0f, INFINITY));
     RT_HIP(ctx, sc->poly_bound.upload(poly_bound));
     RT_HIP(ctx, sc->cone_bound.upload(cone_bound));
+    cluster_boxes(std::vector<LeafSphere>(), bnd, 0u, bnd_box);  // (the records of the other blocks, and the padding: boxes that hold everything)
+    for (int k = 0; k < 8; ++k) {
+        poly_box.push_back(make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f));
+        poly_box.push_back(make_float4(INFINITY, INFINITY, INFINITY, 0.0f));
+    }
+    RT_HIP(ctx, sc->bnd_box.upload(bnd_box));
+    RT_HIP(ctx, sc->poly_box.upload(poly_box));
     RT_HIP(ctx, sc->vpos.upload(vpos));
     {
         // The ray-independent part of the cone and polygon tests, by the device's own arithmetic
@@ -734,6 +751,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.cone_items = sc->cone_items.p;
     d.poly_rec = sc->poly_rec.p;
     d.poly_bound = sc->poly_bound.p;
+    d.bnd_box = (const float4*)sc->bnd_box.p;
+    d.poly_box = sc->poly_box.p;
     d.cone_bound = sc->cone_bound.p;
     d.cones = sc->cones.p;
     d.vpos = sc->vpos.p;

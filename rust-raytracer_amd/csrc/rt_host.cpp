@@ -132,6 +132,12 @@ extern "C" int rt_debug_bound(uint32_t kind, const rt_cone* cone, const rt_verte
     return 0;
 }
 
+extern "C" int rt_debug_polygon_box(const rt_vertex* verts, uint32_t n_verts, float* out6) {
+    float c[3], r;
+    if (!out6 || !verts || n_verts < 3) return 0;
+    return polygon_bound(verts, 0, n_verts, c, &r, out6) ? 1 : 0;
+}
+
 extern "C" void rt_camera_basis(const rt_view* view, float* out9) {
     Camera c = camera_basis(*view);
     memcpy(out9, c.forward, 12);

@@ -1,5 +1,6 @@
 // Internal host-side declarations shared by the translation units of librtamd.so.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <functional>
 #include <string>
@@ -30,17 +31,27 @@ struct LeafSphere {      // a sphere, or the sphere that stands in for a polygon
     float r;
     uint32_t prim, pos;  // primitive id, position in the leaf's list
     uint32_t a0, a1;     // polygons: first vertex, vertex count; cylinders: cone index, -
+    // polygons: the box of polygon_bound (everything by default: an entry without one is never ruled out by it)
+    float lo[3] = {-INFINITY, -INFINITY, -INFINITY}, hi[3] = {INFINITY, INFINITY, INFINITY};
 };
 // Re-orders `v` spatially, pads it to a multiple of 8 entries (padding = copies of entries with
 // bit 31 of `pos` set), and appends the run's block of bounding records to `bnd` (4 floats each);
 // returns the index of the block's header record.
-uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd);
+// max_level (4 or 5): the highest level that may be the run's top level (the device walks five-level runs of
+// polygons only).
+uint32_t cluster_spheres(std::vector<LeafSphere>& v, std::vector<float>& bnd, int max_level = 4);
 // The bounding record {C, q} of one entry alone (q = inf when its radius is not finite: never culled).
 void sphere_record(const LeafSphere& e, float out[4]);
 // Sphere {c, r} such that whenever Polygon::intersect (reference src/polygon.rs:58-293) accepts
 // a ray, the ray's line passes within r + 1.1e-5 |src - c| of c.  False if no such bound exists
 // (coordinates that are not finite).
-bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, float c[3], float* r);
+// box6 (may be null): an axis-aligned box {lo xyz, hi xyz} about c such that the accepted point src + ray t lies inside
+// it widened by 1.1e-5 |src - c| on every side.
+bool polygon_bound(const rt_vertex* vertices, uint32_t first, uint32_t count, float c[3], float* r, float* box6 = nullptr);
+// Box records beside the sphere records of the block cluster_spheres appended at header `h` for `v` (as it left
+// them): `box` holds 8 floats {lo xyz, -, hi xyz, -} per record of `bnd`, same index; a record's box is the union of
+// the boxes of the entries below it.  Records of other blocks keep (or get) the box that holds everything.
+void cluster_boxes(const std::vector<LeafSphere>& v, const std::vector<float>& bnd, uint32_t h, std::vector<float>& box);
 // The same for a cone with equal radii and a query with near >= 0 (Cone::intersect, reference
 // src/cone.rs:97-221): the line passes within r + 1.011e-3 |src - c| of c.  False for any other
 // cone (its quadratic's leading coefficient can cancel, and then no such bound holds).

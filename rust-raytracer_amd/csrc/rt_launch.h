@@ -47,7 +47,7 @@ struct DevScene {
     // Leaf primitive lists, one run per kind and leaf, each in the builder's list order.
     const float4* sph;         // sphere runs: {centre, r*r}; every run padded to a multiple of 8 entries
     const uint2* sph_id;       // parallel to sph: {primitive, position in the leaf's list}
-    const float4* bnd;         // per sphere run: header + bounding records {centre, q}, 8-ary, up to 4 levels
+    const float4* bnd;         // per sphere run: header + bounding records {centre, q}, 8-ary, up to 5 levels
     const uint4* cone_items;   // {primitive, position in the leaf's list, cone index, -}
     // polygon runs, 64 bytes (one cache line, one round trip) per entry: {primitive, position in the
     // leaf's list, first vertex, vertex count} {plane normal, edge-loop coordinates} (polygon_plane)
@@ -55,6 +55,12 @@ struct DevScene {
     const float4* poly_rec;
     const float4* poly_bound;  // beside poly_rec: bounding record {C, q} of the polygon alone
     const float4* cone_bound;  // beside cone_items: the same for a cylinder; q = inf for a cone proper
+    // Box records of polygon runs: 2 per record of bnd, same index, {lo, -} {hi, -} (boxes that hold everything for
+    // the records of other runs), and 2 per entry of poly_rec for the polygon alone.  Every point at which the
+    // reference can accept a polygon below a record lies inside its box widened by 1.1e-5 |src - C| (leaf_cluster.cpp
+    // polygon_bound); flat groups -- a terrain patch, a wall -- are held far tighter by a box than by a sphere.
+    const float4* bnd_box;
+    const float4* poly_box;
     const float4* cones;       // 4 per entry of cone_items: {base, base radius} {w, axis length} {u, radius difference} {v, -} (cone_frame)
     const float4* vpos;        // per vertex {point, 0}
     const float4* vnrm;        // per vertex {normal, 0}

@@ -70,6 +70,11 @@ RT_DEV uint2 ld_u2(const uint2* p, uint32_t i) {
     }
 }
 
+// Per-lane LDS words of a run's walk: one stack entry per level of bounding records (four, or five for a run with
+// five levels), then the queue of level-1 groups.
+constexpr uint32_t LANE_STACK = 4;
+constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - LANE_STACK;
+
 struct Hit {
     float dist;
     uint32_t prim;
@@ -79,7 +84,7 @@ struct Hit {
 // Nearest hit of one leaf visit.
 struct LeafBest {
     static constexpr bool kQueued = false;        // cone and polygon tests run where their candidates are found
-    static constexpr uint32_t kLaneQueue = RT_LANE_WORDS - 4;  // level-1 groups a lane's walk of a run queues before it drains them (LANE_QUEUE)
+    static constexpr uint32_t kLaneQueue = LANE_QUEUE;  // level-1 groups a lane's walk of a run queues before it drains them (LANE_QUEUE)
     bool have;
     float t;
     uint32_t pos;     // position in the leaf's primitive list (tie-break)
@@ -303,7 +308,7 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
 // ---------------------------------------------------------------------------------------
 // Culled walk of a big sphere run, one lane = one ray, no wave-wide coupling.  The run's
 // entries are grouped 8 to a level-1 record, 8 level-1 records to a level-2 record, ... up to
-// level 4; each record is a bounding sphere {C, q} built on the host (leaf_cluster.cpp, which
+// level 5; each record is a bounding sphere {C, q} built on the host (leaf_cluster.cpp, which
 // also derives the bound and the layout).  A group is skipped only when the reference's test
 // cannot accept ANY sphere inside it:
 //     |E|^2 * (1 - beta) - q > (n . E)^2,   E = src - C,  n = ray / |ray|,  beta = 2.2e-5,
@@ -316,18 +321,19 @@ RT_DEV void leaf_polygons(const DevScene& S, uint32_t first, uint32_t count, F3 
 //
 // The walk is split in two loops so that the lanes of a wave run the same code on different
 // data: first a depth-first descent whose only step is "test the 8 records of one group"
-// (pending sibling masks sit on a 4-entry per-lane stack in LDS), which queues {level-1 group,
+// (pending sibling masks sit on a per-lane stack in LDS, one entry per level), which queues {level-1 group,
 // mask of live records}; then the queue is drained, each step testing the 8 spheres of one
 // live level-1 record with the reference's own arithmetic.
 // ---------------------------------------------------------------------------------------
+#ifndef RT_POLY_BOXES
+#define RT_POLY_BOXES 1  // polygon runs are walked by their box records (BoxRay) where the ray can use them
+#endif
 constexpr float CULL_ONE_MINUS_BETA = 0.999978f;  // 1 - 2.2e-5
 constexpr float CULL_BETA = 2.2e-5f;
 #ifndef RT_CULL_MIN_SPHERES
 #define RT_CULL_MIN_SPHERES 24
 #endif
 constexpr uint32_t CULL_MIN_SPHERES = RT_CULL_MIN_SPHERES;  // shorter runs are walked eight entries at a time
-constexpr uint32_t LANE_STACK = 4;                   // per-lane LDS words: 4 stack entries, then the queue
-constexpr uint32_t LANE_QUEUE = RT_LANE_WORDS - LANE_STACK;
 
 // BEHIND adds the second way out, for rays that start among the spheres: the whole bounding
 // sphere lies behind the ray's origin,
@@ -393,6 +399,56 @@ RT_DEV uint32_t expand8(const float4* base, uint32_t valid, F3 src, F3 n, Ctr& c
     uint32_t m = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) m |= bound_may_hit<BEHIND>(r[k], src, n) ? (1u << k) : 0u;
+    ctr.bound_tests(8);
+    if constexpr (Ctr::kEnabled) {
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true)))
+            ctr.lane_slots(8 * 64);
+    }
+    return valid >= 8u ? m : (m & ((1u << valid) - 1u));
+}
+
+// Box records (polygon runs).  A record's box {lo, hi} holds every point X = src + ray t, t >= 0, at which the
+// reference can accept a polygon below it, once widened by w >= 1.1e-5 |src - C| for every such polygon's centre C
+// (leaf_cluster.cpp polygon_bound, cluster_boxes); the ray's query has near >= 0.  So a ray whose forward half
+// misses the widened box cannot be accepted by anything below the record.  The slab quotients are formed as
+// aabb_quick forms them, A = fl(corner * inv - P), with the widening folded into P per ray and run (BoxRay:
+// P_lo = fl(p + w inv), P_hi = fl(p - w inv), which moves each quotient outwards whatever inv's sign); each A is
+// within 2.1u |A| + 2.1u |p| of the exact quotient, and the record is dropped only when the entry and exit
+// parameters n, f are apart (n > f) or behind the origin (f < 0) by more than 10u max(|n|, |f|) + 6.3u max|p|.
+// Only for rays aabb_quick can take (RayInv::quick: no zero component, nothing near overflow); the others keep
+// the sphere records.  A NaN keeps the record; a box that holds everything gives n = -inf, f = +inf.
+struct BoxRay {
+    F3 inv, plo, phi;
+    float slack;
+    RT_DEV void set(const RayInv& ri, float w) {
+        inv = ri.inv;
+        plo = f3(__builtin_fmaf(w, ri.inv.x, ri.p.x), __builtin_fmaf(w, ri.inv.y, ri.p.y), __builtin_fmaf(w, ri.inv.z, ri.p.z));
+        phi = f3(__builtin_fmaf(-w, ri.inv.x, ri.p.x), __builtin_fmaf(-w, ri.inv.y, ri.p.y), __builtin_fmaf(-w, ri.inv.z, ri.p.z));
+        slack = 3.0f * ri.slack;
+    }
+    RT_DEV bool may_hit(float4 lo, float4 hi) const {
+        const float ax = __builtin_fmaf(lo.x, inv.x, -plo.x), bx = __builtin_fmaf(hi.x, inv.x, -phi.x);
+        const float ay = __builtin_fmaf(lo.y, inv.y, -plo.y), by = __builtin_fmaf(hi.y, inv.y, -phi.y);
+        const float az = __builtin_fmaf(lo.z, inv.z, -plo.z), bz = __builtin_fmaf(hi.z, inv.z, -phi.z);
+        const float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const float m = __builtin_fmaf(fmaxf(fabsf(f), fabsf(n)), 6e-7f, slack);
+        return !(n - f > m) && !(f < -m);
+    }
+};
+
+// Live mask of the box records base2[0 .. 16) = 8 x {lo, hi}, of which the first `valid` exist.
+template <class Ctr>
+RT_DEV uint32_t expand8_box(const float4* base2, uint32_t valid, const BoxRay& br, Ctr& ctr) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {  // (two batches of four boxes: eight loads in flight, as for the sphere records)
+        float4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = base2[half * 8 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m |= br.may_hit(r[2 * k], r[2 * k + 1]) ? (1u << (half * 4 + k)) : 0u;
+    }
     ctr.bound_tests(8);
     if constexpr (Ctr::kEnabled) {
         if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(true)))
@@ -552,24 +608,38 @@ struct NoOccluder {
 template <int KIND, bool BEHIND, bool LREC, class LB, class Ctr, class Occ, class St>
 RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uint32_t header, F3 src, F3 ray, F3 un, float a,
                           float near, uint32_t ignore, LB& lb, Ctr& ctr, uint32_t* lq, uint32_t stride, Occ& occ,
-                          const St& st, lds_cf4_ptr lrec) {
+                          const St& st, lds_cf4_ptr lrec, const RayInv& ri) {
     const float4 hf = LREC ? ld_lds(lrec, header) : S.bnd[header];
+    const float4 whole = LREC ? ld_lds(lrec, header + 1u) : S.bnd[header + 1u];
     ctr.bound_tests(1);
-    if (!bound_may_hit<BEHIND>(LREC ? ld_lds(lrec, header + 1u) : S.bnd[header + 1u], src, un)) return;  // misses the whole run
+    if (!bound_may_hit<BEHIND>(whole, src, un)) return;  // misses the whole run
+    // Polygon runs: by the box records where the ray can use them (BoxRay); every polygon's centre lies inside the
+    // run's sphere, so |src - C| <= |src - C_run| + R_run (R_run^2 <= q).
+    bool boxes = false;
+    BoxRay br;
+    if constexpr (KIND == 1 && !LREC && RT_POLY_BOXES != 0) {
+        boxes = ri.quick && near >= 0.0f;  // (the box test looks at the ray's forward half only)
+        const float ex = src.x - whole.x, ey = src.y - whole.y, ez = src.z - whole.z;
+        br.set(ri, 1.2e-5f * (sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + sqrtf(whole.w)));
+    }
     const uint32_t rot = threadIdx.x & 7u;
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
                    off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w) & 7u;
-    const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
-    auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : off4)); };
-    auto level_n = [&](uint32_t L) { return L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : n4)); };
+    const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3, n5 = (n4 + 7u) >> 3;
+    const uint32_t off5 = off4 + n4;  // (a block's levels follow one another)
+    auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : (L == 4u ? off4 : off5))); };
+    auto level_n = [&](uint32_t L) { return L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : (L == 4u ? n4 : n5))); };
     uint32_t qn = 0;
+    // (only polygon runs are built with five levels: such a run's stack takes a word from its queue)
+    const uint32_t qbase = (KIND == 1 && top > LANE_STACK) ? top : LANE_STACK;  // the queue's first lane word
+    const uint32_t qcap = LB::kLaneQueue - (qbase - LANE_STACK);
 
     auto drain = [&]() {
         uint32_t g = 0, m = 0;
         while (m != 0u || qn != 0u) {
             if (m == 0u) {
                 --qn;
-                const uint32_t e = lq[(LANE_STACK + qn) * stride];
+                const uint32_t e = lq[(qbase + qn) * stride];
                 g = e >> 8;
                 m = e & 0xffu;
             }
@@ -578,7 +648,9 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             if constexpr (KIND != 0 && LB::kQueued) {
                 // the eight items' own records here; the tests of those that pass, later, by whichever lanes are free
                 const uint32_t i0 = first + (g * 8u + k) * 8u;
-                uint32_t pm = expand8<BEHIND>((KIND == 1 ? S.poly_bound : S.cone_bound) + i0, 8u, src, un, ctr);
+                uint32_t pm;
+                if (KIND == 1 && boxes) pm = expand8_box(S.poly_box + 2u * i0, 8u, br, ctr);
+                else pm = expand8<BEHIND>((KIND == 1 ? S.poly_bound : S.cone_bound) + i0, 8u, src, un, ctr);
                 while (pm != 0u) {
                     const uint32_t kk = (uint32_t)__builtin_ctz(pm);
                     pm &= pm - 1u;
@@ -607,9 +679,9 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             if (L == 1u) {  // g is a level-1 group: queue its live records
                 if (m != 0u) {
                     ctr.bound_passes((uint32_t)__builtin_popcount(m));
-                    lq[(LANE_STACK + qn) * stride] = (g << 8) | m;
+                    lq[(qbase + qn) * stride] = (g << 8) | m;
                     ++qn;
-                    if (qn == LB::kLaneQueue) {
+                    if (qn == qcap) {
                         drain();
                         if constexpr (Occ::kOn) {
                             if (occ.hit) return;
@@ -635,6 +707,7 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
             g = g * 8u + k;  // record g*8+k of level L = group of that index one level down
             L -= 1u;
             if constexpr (LREC) m = expand8_lds<BEHIND>(lrec, level_off(L) + g * 8u, level_n(L) - g * 8u, rot, src, un, ctr);
+            else if (KIND == 1 && boxes) m = expand8_box(S.bnd_box + 2u * (level_off(L) + g * 8u), level_n(L) - g * 8u, br, ctr);
             else m = expand8<BEHIND>(S.bnd + level_off(L) + g * 8u, level_n(L) - g * 8u, src, un, ctr);
         }
     }
@@ -840,19 +913,19 @@ struct KdWalk {
             }
             if constexpr (MODE != 0) {
                 if (q2.y >= CULL_MIN_SPHERES && tame) {  // big sphere run: this lane's own walk of its bounding records
-                    leaf_run_lane<0, MODE == 2, (CULL & 12) == 12>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec);
+                    leaf_run_lane<0, MODE == 2, (CULL & 12) == 12>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec, ri);
                     q2.y = 0u;
                 }
                 RT_PHASE(1);  // sphere hierarchy
                 if constexpr (!LEAN) {
                     if (q3.w != 0xffffffffu && tame && !occ.decided(st, lb)) {  // polygon run with bounding records
-                        leaf_run_lane<1, MODE == 2, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec);
+                        leaf_run_lane<1, MODE == 2, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec, ri);
                         q3.y = 0u;
                     }
                     RT_PHASE(2);  // polygon hierarchy
                     if (cyl_n != 0u && tame && near >= 0.0f && !occ.decided(st, lb)) {  // cylinder run with bounding records
                         leaf_run_lane<2, MODE == 2, false>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, un, a, near, ignore, lb, ctr,
-                                                           lane_words, stride, occ, st, lrec);
+                                                           lane_words, stride, occ, st, lrec, ri);
                         cyl_n = 0u;
                     }
                     RT_PHASE(3);  // cylinder hierarchy
@@ -969,7 +1042,7 @@ RT_DEV uint32_t lane_index() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_a
 
 struct HitList {
     static constexpr bool kQueued = true;
-    static constexpr uint32_t kLaneQueue = RT_LANE_WORDS - 4;
+    static constexpr uint32_t kLaneQueue = LANE_QUEUE;
     // hit k of lane j of this wave at wave0[k * stride + j]: {primitive, bits of the distance}; entry HIT_CAP: {hits the
     // lane has (more than HIT_CAP: some were dropped), lane 0's: items in the wave's queue}
     uint2* wave0;
@@ -1207,9 +1280,10 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
     if (!b.may_hit(whole.x, whole.y, whole.z, whole.w)) return true;
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
                    off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w) & 7u;
-    const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3;
-    auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : off4)); };
-    auto level_n = [&](uint32_t L) { return L == 0u ? count : (L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : n4))); };
+    const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3, n5 = (n4 + 7u) >> 3;
+    const uint32_t off5 = off4 + n4;
+    auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : (L == 4u ? off4 : off5))); };
+    auto level_n = [&](uint32_t L) { return L == 0u ? count : (L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : (L == 4u ? n4 : n5)))); };
     auto word = [&](uint32_t j) -> uint32_t& { return ww[(j >> 6) * stride + (j & 63u)]; };
     const uint32_t n_top = level_n(top);
     if (n_top > BEAM_PENDING) return false;
@@ -1417,19 +1491,19 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
             if (q3.w != 0xffffffffu) q3.y = 0u;
         } else {
         if (q2.y >= CULL_MIN_SPHERES) {  // spheres, through their bounding records
-            leaf_run_lane<0, BEHIND, false>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+            leaf_run_lane<0, BEHIND, false>(S, q2.x, q2.y, q3.z, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec, ri);
             q2.y = 0u;
         }
         RT_PHASE(1);
         if (q3.w != 0xffffffffu) {  // polygons
-            leaf_run_lane<1, BEHIND, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+            leaf_run_lane<1, BEHIND, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec, ri);
             hl.template flush<1>(S, src, ray, near, ignore, ctr);
             q3.y = 0u;
         }
         RT_PHASE(2);
         if (S.all_w != 0xffffffffu) {  // cylinders (the cone items before q2.z)
             const uint32_t cyl_n = __float_as_uint(S.bnd[S.all_w].w) >> 3;
-            leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec);
+            leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec, ri);
             hl.template flush<2>(S, src, ray, near, ignore, ctr);
         }
         }

@@ -1,5 +1,5 @@
 """The spheres that stand in for cylinders and polygons in the leaf walk's bounding records
-(leaf_cluster.cpp cylinder_bound / polygon_bound) against the oracle's shape tests, on the CPU:
+(leaf_cluster.cpp cylinder_bound / polygon_bound), and the boxes that stand in for polygons, against the oracle's shape tests, on the CPU:
 whenever the reference's test accepts a ray, the accepted point must lie inside the sphere plus
 the slack proportional to the origin's distance that the records allow for.  Rays are aimed to
 graze, from origins up to 10^4 object sizes away, where the f32 discriminant accepts lines well
@@ -129,6 +129,52 @@ def test_polygon_stand_in_sphere_holds_every_accepted_point(oracle):
     assert accepted > 20000
     assert worst <= 0.0, worst
     assert worst_guard < 0.5, worst_guard
+
+
+def test_polygon_stand_in_box_holds_every_accepted_point(oracle):
+    """The box records of polygon runs (leaf_cluster.cpp polygon_bound's box, rt_traverse.h BoxRay): whenever the
+    reference's test accepts a ray, the accepted point lies inside the polygon's box widened by 1.1e-5 |src - centre|
+    on every side -- also for slivers, whose plane normal is rounding noise, for axis-aligned polygons (a box without
+    thickness on one axis) and for rays almost inside the plane, from up to 10^4 polygon sizes away."""
+    rng = np.random.default_rng(16)
+    worst, accepted, thin = -1.0, 0, 0
+    for k in range(240):
+        nv = 3 if k % 3 else 4
+        size = 10.0 ** rng.uniform(-2, 1)
+        centre = rng.normal(size=3) * 10.0 ** rng.uniform(-1, 2)
+        v = centre + rng.normal(size=(nv, 3)) * size
+        if k % 5 == 1:
+            v[2] = v[0] + (v[1] - v[0]) * rng.uniform(0.2, 0.8) + rng.normal(size=3) * size * 1e-6
+        elif k % 5 == 2:
+            v[:, rng.integers(0, 3)] = centre[rng.integers(0, 3)]
+            thin += 1
+        v = v.astype(np.float32)
+        verts6 = np.concatenate([v, np.tile(np.array([[0, 0, 1]], np.float32), (nv, 1))], axis=1)
+        box = rtamd.debug_polygon_box(verts6)
+        assert box is not None
+        lo, hi = box[:3].astype(np.float64), box[3:].astype(np.float64)
+        assert (lo <= v.min(0)).all() and (hi >= v.max(0)).all()
+        c = 0.5 * (lo + hi)
+        n = 3000
+        wts = rng.dirichlet(np.ones(nv), n)
+        wts = np.where((rng.random((n, 1)) < 0.3), np.eye(nv)[rng.integers(0, nv, n)], wts)
+        tgt = wts @ v.astype(np.float64)
+        far = 10.0 ** rng.uniform(-1, 4, (n, 1)) * size
+        d = rng.normal(size=(n, 3))
+        inpl = (v[1].astype(np.float64) - v[0])[None, :] + rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-8, -1, (n, 1)) * size
+        d = np.where(rng.random((n, 1)) < 0.3, inpl, d)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        src = (tgt - d * far).astype(np.float32)
+        ray = (d * rng.choice([1.0, 0.03, 40.0], (n, 1))).astype(np.float32)
+        hit, x = accepted_points(oracle, KIND_POLYGON, None, verts6, src, ray, np.zeros(n, np.float32))
+        if hit.any():
+            w = 1.1e-5 * np.linalg.norm(src[hit].astype(np.float64) - c, axis=1)[:, None]
+            out = np.maximum(lo - x[hit], x[hit] - hi)  # how far outside the box, per axis
+            worst = max(worst, float((out / np.maximum(w, 1e-300)).max()))
+            accepted += int(hit.sum())
+    assert accepted > 20000 and thin > 20
+    assert worst <= 1.0, worst  # (inside the widened box; > 0: accepted points do leave the box itself)
+    print("accepted points reach %.3f of the widening the rays are given" % worst)
 
 
 def test_sphere_acceptance_margin_of_the_bounding_records(oracle):
