@@ -776,6 +776,8 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.all_w = all_rec[0].x;
     d.all_q2 = all_rec[1];
     d.all_q3 = all_rec[2];
+    d.beam_shadow = (d.hit_walk != 0u && all_rec[2].w != 0xffffffffu && all_rec[1].y < 24u && all_rec[0].x == 0xffffffffu) ? 1u : 0u;
+    if (const char* e = getenv("RTAMD_BEAM_SHADOW")) d.beam_shadow = (d.beam_shadow != 0u && atoi(e) != 0) ? 1u : 0u;
     d.nodes_lds = (d.lean == 0u && (size_t)d.n_nodes * 64u <= RT_NODE_LDS_BYTES) ? 1u : 0u;
     // Measured at 3840x2160 (k_shadow, ms, lanes waiting for their wave / lanes taking the next ray): rings 4
     // (largest leaf 212) 23.1 / 18.4; lathe 96 at 1920x1080 (273) 2.41 / 2.34; mount 8 (45685) 6.4 / 8.0;

@@ -1125,11 +1125,14 @@ static uint32_t g_cus = 256;  // compute units of the device (init_kernels)
 #ifndef RT_BEAM
 #define RT_BEAM 1
 #endif
+// (the same for shadow rays towards their light, on scenes of polygons: built, parity-green, measured slower -- mount 8
+// with 8 lights 3.79 -> 4.21 ms, lathe 0.68 -> 0.71 -- and left out of the library)
 #ifndef RT_BEAM_SHADOW
 #define RT_BEAM_SHADOW 0
 #endif
 constexpr int GEN_ID = 2 | 8 | 16, GEN_SH = 2 | 8 | 16;
-constexpr int HITS_ID = 2 | 64, HITS_SH = 2 | 64 | (RT_BEAM_SHADOW ? 128 : 0);  // the hit-list walk (DevScene::hit_walk): deeper levels, shadow rays (+ 128: beam_runs, towards the light)
+constexpr int HITS_ID = 2 | 64, HITS_SH = 2 | 64;  // the hit-list walk (DevScene::hit_walk): deeper levels, shadow rays
+constexpr int HITS_SHB = 2 | 64 | 128;        // shadow rays of scenes of polygons (DevScene::beam_shadow): 64 at a time towards their light where they lie together (beam_runs)
 constexpr int HITS_I0L = 1 | 64 | 128 | 256;  // camera rays of the other scenes with the hit-list tables: by the wave where that is cheap, else leaf by leaf
 constexpr int HITS_I0 = 1 | 64 | (RT_BEAM ? 128 : 0);  // ... and camera rays (+ 128: a wave's rays leave one point, beam_runs)
 // Camera rays (level 0) by the hit-list walk: only where the partition hardly partitions (DevScene::hit_walk_level0,
@@ -1200,6 +1203,9 @@ hipError_t init_kernels() {
                          (const void*)k_intersect<true, HITS_I0L, NoCounters>,
 #endif
                          (const void*)k_shadow<HITS_SH, NoCounters>, (const void*)k_shadow<HITS_SH, WorkCounters>,
+#if RT_BEAM_SHADOW
+                         (const void*)k_shadow<HITS_SHB, NoCounters>,
+#endif
                          (const void*)k_deep<HITS_ID, NoCounters>,
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>, (const void*)k_debug_intersect<HITS_ID>};
     for (const void* f : fns) {
@@ -1350,14 +1356,18 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
     // shadow rays start on a surface, among the primitives, at every level: the behind-origin test pays
     const int mode = cull ? 2 : 0;
     const bool lean = A.scene.lean != 0;
+    const bool beam = RT_BEAM_SHADOW != 0 && hit_walk && !work && A.scene.beam_shadow != 0u;
     if (variant) {
-        if (hit_walk) *variant = HITS_SH;
+        if (hit_walk) *variant = beam ? HITS_SHB : HITS_SH;
         else if (work || mode == 0) *variant = mode;
         else if (A.shadow_mode == 1 || A.shadow_mode == 2) *variant = lean ? LEAN_SH : 2;
         else *variant = lean ? LEAN_SH : (gen_stays ? GEN_SH : 2);
     }
     if (hit_walk) {
         if (work) hipLaunchKernelGGL((k_shadow<HITS_SH, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+#if RT_BEAM_SHADOW
+        else if (beam) hipLaunchKernelGGL((k_shadow<HITS_SHB, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+#endif
         else hipLaunchKernelGGL((k_shadow<HITS_SH, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
     } else if (work) {
         if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);

@@ -1247,9 +1247,38 @@ struct Beam {
     F3 apex, axis;
     float cos_lo, sin_hi;
     float eps;    // the lines pass the apex within this
+    float line_slack;  // box tests: how far a ray's line strays, inside the scene, from the line the test takes for it
     F3 org;       // one ray's origin, and how far from it the other origins lie at most (a record's slack grows
     float spread; // with the distance from the ray's OWN origin to the record's centre)
     float reach;  // what lies farther than this from the apex, on the axis' side, lies behind every origin (inf: nothing does)
+    // Rays from one point (the apex) against a box record: per axis the range [ilo, ihi] of the rays' reciprocal
+    // direction components, rounded outwards, or `open` when they do not all have one sign (then that axis rules
+    // nothing out).  A ray that meets the widened box has, on every axis, its entry parameter at least the smallest
+    // and its exit parameter at most the largest of the four products (slab side - apex) * {ilo, ihi} -- a product is
+    // monotone in the reciprocal -- so the box is dropped when the largest of those lower ends exceeds the smallest of
+    // the upper ends, or that one lies behind the apex, by more than the products' rounding (2e-6 of the larger).
+    // Rays that make for the apex instead (shadow rays): the same with the lines taken from the apex to the origins,
+    // direction origin - apex, so that every origin sits at parameter 1: what a ray can hit lies at parameters up to 1
+    // (towards the apex and beyond it, on the far side, at negative ones), and a box whose entry lies beyond 1 for every
+    // ray lies behind every origin (`towards`; the test "exit behind the apex" does not apply then).
+    F3 ilo, ihi;
+    bool open_x, open_y, open_z, towards;
+    RT_DEV void slab(float lo, float hi, float o, float i0, float i1, bool open, float& enter, float& leave) const {
+        if (open) return;
+        const float a = lo - o, b = hi - o;
+        const float p0 = a * i0, p1 = a * i1, p2 = b * i0, p3 = b * i1;
+        enter = fmaxf(enter, fminf(fminf(p0, p1), fminf(p2, p3)));
+        leave = fminf(leave, fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)));
+    }
+    RT_DEV bool box_may_hit(float4 lo, float4 hi, float w) const {
+        float enter = -INFINITY, leave = INFINITY;
+        slab(lo.x - w, hi.x + w, apex.x, ilo.x, ihi.x, open_x, enter, leave);
+        slab(lo.y - w, hi.y + w, apex.y, ilo.y, ihi.y, open_y, enter, leave);
+        slab(lo.z - w, hi.z + w, apex.z, ilo.z, ihi.z, open_z, enter, leave);
+        const float m = __builtin_fmaf(fmaxf(fabsf(enter), fabsf(leave)), 2e-6f, 1e-30f);
+        if (towards) return !(enter - leave > m) && !(enter > 1.00001f);
+        return !(enter - leave > m) && !(leave < -m);  // (a NaN, an infinite box: kept)
+    }
     RT_DEV bool may_hit(float cx, float cy, float cz, float q) const {
         const float dx = cx - apex.x, dy = cy - apex.y, dz = cz - apex.z;
         const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -1273,11 +1302,20 @@ RT_DEV uint32_t below_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_
 
 // The candidate entries of one run (KIND as leaf_run_lane's), appended to cand[0 .. n_cand) as KIND << 30 | entry.
 // ww: the wave's lane words (word j at ww[(j >> 6) * stride + (j & 63)]).  All 64 lanes; false: no room.
-template <int KIND, class Ctr>
+// BOX (polygon runs, rays from one point): by the run's box records (DevScene::bnd_box, poly_box) instead.
+template <int KIND, bool BOX, class Ctr>
 RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint32_t count, uint32_t header, uint32_t* ww,
-                         uint32_t stride, uint32_t* cand, uint32_t& n_cand, uint32_t lane, Ctr& ctr) {
+                         uint32_t stride, uint32_t& n_cand, uint32_t lane, Ctr& ctr) {
     const float4 hf = ld_f4<true>(S.bnd, header), whole = ld_f4<true>(S.bnd, header + 1u);
     if (!b.may_hit(whole.x, whole.y, whole.z, whole.w)) return true;
+    // (as BoxRay's: every polygon's centre lies in the run's sphere, every origin within `spread` of `org`; rays that
+    // make for the apex miss it by up to `eps` and the line from the apex through their origin by no more between the
+    // two, by up to eps per `reach` of distance beyond them)
+    float box_w = 0.0f;
+    if constexpr (BOX) {
+        const float ex = b.org.x - whole.x, ey = b.org.y - whole.y, ez = b.org.z - whole.z;
+        box_w = 1.2e-5f * (sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + b.spread + sqrtf(whole.w)) + b.line_slack;
+    }
     const uint32_t off1 = header + 2u, off2 = __float_as_uint(hf.x), off3 = __float_as_uint(hf.y),
                    off4 = __float_as_uint(hf.z), top = __float_as_uint(hf.w) & 7u;
     const uint32_t n1 = (count + 7u) >> 3, n2 = (n1 + 7u) >> 3, n3 = (n2 + 7u) >> 3, n4 = (n3 + 7u) >> 3, n5 = (n4 + 7u) >> 3;
@@ -1286,7 +1324,7 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
     auto level_n = [&](uint32_t L) { return L == 0u ? count : (L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : (L == 4u ? n4 : n5)))); };
     auto word = [&](uint32_t j) -> uint32_t& { return ww[(j >> 6) * stride + (j & 63u)]; };
     const uint32_t n_top = level_n(top);
-    if (n_top > BEAM_PENDING) return false;
+    if (n_top + n_cand > BEAM_PENDING) return false;
     for (uint32_t i = lane; i < n_top; i += 64u) word(i) = (top << 28) | i;
     uint32_t size = n_top;
     while (size != 0u) {
@@ -1295,9 +1333,13 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
         const uint32_t e = word(size + (lane < n ? lane : 0u));
         const bool mine = lane < n && e != 0xffffffffu;
         const uint32_t L = e >> 28, i = e & 0x0fffffffu;
-        float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY);
+        float4 rec = make_float4(0.0f, 0.0f, 0.0f, INFINITY), rec_hi = rec;
         if (mine) {
-            if (L != 0u) {
+            if constexpr (BOX) {
+                const float4* at = L != 0u ? S.bnd_box + 2u * (level_off(L) + i) : S.poly_box + 2u * (first + i);
+                rec = at[0];
+                rec_hi = at[1];
+            } else if (L != 0u) {
                 rec = S.bnd[level_off(L) + i];
             } else if constexpr (KIND == 0) {
                 rec = S.sph[first + i];
@@ -1306,17 +1348,18 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
                 rec = (KIND == 1 ? S.poly_bound : S.cone_bound)[first + i];
             }
         }
-        const bool pass = mine && b.may_hit(rec.x, rec.y, rec.z, rec.w);
+        const bool pass = mine && (BOX ? b.box_may_hit(rec, rec_hi, box_w) : b.may_hit(rec.x, rec.y, rec.z, rec.w));
         if (mine) ctr.bound_tests(1);
         if (lane == 0u) ctr.lane_slots(64);
         const uint64_t m_entry = __ballot(pass && L == 0u), m_inner = __ballot(pass && L != 0u);
         const uint32_t n_entry = (uint32_t)__popcll(m_entry), n_inner = (uint32_t)__popcll(m_inner);
         if (lane == 0u) RT_HITSTAT(11, n);
-        if (n_cand + n_entry > WQ_CAP || size + 8u * n_inner > BEAM_PENDING) {
+        // (the candidates are kept at the far end of the same words, last word first)
+        if (n_cand + n_entry > WQ_CAP || size + 8u * n_inner + n_cand + n_entry > BEAM_PENDING) {
             if (lane == 0u) RT_HITSTAT(n_cand + n_entry > WQ_CAP ? 8 : 9, 1u);
             return false;
         }
-        if (pass && L == 0u) cand[n_cand + below_in(m_entry)] = ((uint32_t)KIND << 30) | (first + i);
+        if (pass && L == 0u) word(BEAM_PENDING - 1u - (n_cand + below_in(m_entry))) = ((uint32_t)KIND << 30) | (first + i);
         n_cand += n_entry;
         if (pass && L != 0u) {
             const uint32_t at = size + 8u * below_in(m_inner), kids = level_n(L - 1u) - 8u * i;
@@ -1335,7 +1378,8 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
 // that length), from origins of their own; what a ray can hit lies between its origin and the apex, or beyond the apex.
 template <bool TO_APEX, bool BEHIND, class LB, class Ctr>
 RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float near, uint32_t ignore, bool tame, bool live,
-                      LB& hl, Ctr& ctr, uint32_t* lane_words, uint32_t stride, F3 apex, float limit, uint32_t most) {
+                      LB& hl, Ctr& ctr, uint32_t* lane_words, uint32_t stride, F3 apex, float limit, uint32_t most, const RayInv& ri) {
+    constexpr bool BOX = RT_POLY_BOXES != 0;  // polygon runs by their box records
     if (__ballot(true) != ~0ull) return false;
     const uint32_t lane = hl.lane;
     const uint64_t m_live = __ballot(live);
@@ -1367,6 +1411,10 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
         }
         b.eps = far * 1e-6f;
         b.reach = __builtin_fmaf(far, 1.00002f, 1e-30f);  // (>= far + 2 eps)
+        // (a ray's direction points at the apex to 3u: over a stretch d of its line that is 3u d, and no point of the
+        // scene is farther than 4 reach + far from an origin)
+        b.line_slack = 1e-6f * (4.0f * S.reach + far);
+        b.towards = true;
     } else {
         b.apex = f3(__shfl(src.x, lead, 64), __shfl(src.y, lead, 64), __shfl(src.z, lead, 64));
         b.axis = lead_un;
@@ -1375,6 +1423,8 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
         b.spread = 0.0f;
         b.eps = 0.0f;
         b.reach = INFINITY;
+        b.line_slack = 0.0f;
+        b.towards = false;
     }
     const F3 cr = cross(lead_un, un);
     float s2 = live ? dot(cr, cr) : 0.0f;
@@ -1393,15 +1443,41 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
         return false;
     }
     b.cos_lo = __builtin_amdgcn_sqrtf(1.0f - b.sin_hi * b.sin_hi) * 0.999999f;
+    if constexpr (BOX) {
+        // the rays' direction components, smallest and largest over the wave; their reciprocals' range
+        float lo[3], hi[3];
+        const float big = 3.0e38f;
+        const F3 dir = TO_APEX ? sub(src, b.apex) : ray;  // (towards the apex: from it to the origin, the origin at parameter 1)
+        lo[0] = live ? dir.x : big; lo[1] = live ? dir.y : big; lo[2] = live ? dir.z : big;
+        hi[0] = live ? dir.x : -big; hi[1] = live ? dir.y : -big; hi[2] = live ? dir.z : -big;
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+            }
+        }
+        float il[3], ih[3];
+        bool open[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            open[k] = !((lo[k] > 1e-30f && hi[k] < 1e30f) || (hi[k] < -1e-30f && lo[k] > -1e30f));
+            const float r0 = 1.0f / hi[k], r1 = 1.0f / lo[k];  // (one sign: r0 <= r1)
+            il[k] = r0 - fabsf(r0) * 4e-7f;
+            ih[k] = r1 + fabsf(r1) * 4e-7f;
+        }
+        b.ilo = f3(il[0], il[1], il[2]);
+        b.ihi = f3(ih[0], ih[1], ih[2]);
+        b.open_x = open[0]; b.open_y = open[1]; b.open_z = open[2];
+    }
     uint32_t* const ww = lane_words - lane;
-    uint32_t* const cand = hl.wq;
     uint32_t n_cand = 0u;
     const uint4 q2 = S.all_q2, q3 = S.all_q3;
-    if (q2.y >= CULL_MIN_SPHERES && !beam_collect<0>(S, b, q2.x, q2.y, q3.z, ww, stride, cand, n_cand, lane, ctr)) return false;
-    if (q3.w != 0xffffffffu && !beam_collect<1>(S, b, q3.x, q3.y, q3.w, ww, stride, cand, n_cand, lane, ctr)) return false;
+    if (q2.y >= CULL_MIN_SPHERES && !beam_collect<0, false>(S, b, q2.x, q2.y, q3.z, ww, stride, n_cand, lane, ctr)) return false;
+    if (q3.w != 0xffffffffu && !beam_collect<1, BOX>(S, b, q3.x, q3.y, q3.w, ww, stride, n_cand, lane, ctr)) return false;
     if (S.all_w != 0xffffffffu) {
         const uint32_t cyl_n = __float_as_uint(ld_f4<true>(S.bnd, S.all_w).w) >> 3;
-        if (!beam_collect<2>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, cand, n_cand, lane, ctr)) return false;
+        if (!beam_collect<2, false>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, n_cand, lane, ctr)) return false;
     }
     if (n_cand > most) {  // (the caller has a cheaper way for so many)
         if (lane == 0u) RT_HITSTAT(8, 1u);
@@ -1412,14 +1488,39 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
         RT_HITSTAT(6, 1u);
         RT_HITSTAT(10, n_cand);
     }
+    // (polygon candidates by their own boxes, where this lane's ray can use them: BoxRay)
+    BoxRay br;
+    bool boxes = false;
+    if constexpr (BOX) {
+        if (q3.w != 0xffffffffu) {
+            const float4 whole = ld_f4<true>(S.bnd, q3.w + 1u);
+            const float ex = src.x - whole.x, ey = src.y - whole.y, ez = src.z - whole.z;
+            br.set(ri, 1.2e-5f * (sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex))) + sqrtf(whole.w)));
+            boxes = ri.quick && near >= 0.0f;
+        }
+    }
     // ---- every candidate to every ray: 64 at a time into registers (each lane fetches one), then handed round
+    uint32_t queued_kind = 0u;
     for (uint32_t c0 = 0u; c0 < n_cand; c0 += 64u) {
         const uint32_t n = n_cand - c0 < 64u ? n_cand - c0 : 64u;
-        const uint32_t my_e = cand[c0 + (lane < n ? lane : 0u)];
+        const uint32_t my_at = BEAM_PENDING - 1u - (c0 + (lane < n ? lane : 0u));
+        const uint32_t my_e = ww[(my_at >> 6) * stride + (my_at & 63u)];
         const uint32_t my_i = my_e & 0x3fffffffu;
-        const float4 my_rec = (my_e >> 30) == 0u ? S.sph[my_i] : ((my_e >> 30) == 1u ? S.poly_bound[my_i] : S.cone_bound[my_i]);
+        float4 my_rec = (my_e >> 30) == 0u ? S.sph[my_i] : ((my_e >> 30) == 1u ? S.poly_bound[my_i] : S.cone_bound[my_i]);
+        float4 my_hi = my_rec;
+        if constexpr (BOX) {
+            if ((my_e >> 30) == 1u) {
+                my_rec = S.poly_box[2u * my_i];
+                my_hi = S.poly_box[2u * my_i + 1u];
+            }
+        }
         for (uint32_t j = 0u; j < n; ++j) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
+            if ((e >> 30) == 2u && queued_kind == 1u) {  // (the candidates come kind by kind: the queue holds one kind at a time)
+                hl.template flush<1>(S, src, ray, near, ignore, ctr);
+                queued_kind = 0u;
+            }
+            if ((e >> 30) != 0u) queued_kind = e >> 30;
             const float4 rec = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.x), (int)j)),
                                            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.y), (int)j)),
                                            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.z), (int)j)),
@@ -1438,12 +1539,24 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
                 float d, c;
                 if (live && sphere_quick(rec.x, rec.y, rec.z, rec.w, src, ray, a, d, c)) sphere_finish<true>(S, i, d, c, a, near, ignore, hl, ctr);
             } else if (kind == 1u) {
-                if (live && bound_may_hit<BEHIND>(rec, src, un)) polygon_item<true, true>(S, i, src, ray, near, ignore, hl, ctr);
+                bool pass = live;
+                if constexpr (BOX) {
+                    const float4 hi = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_hi.x), (int)j)),
+                                                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_hi.y), (int)j)),
+                                                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_hi.z), (int)j)), 0.0f);
+                    pass = pass && (!boxes || br.may_hit(rec, hi));  // (a ray that cannot use the boxes tests the polygon itself)
+                } else {
+                    pass = pass && bound_may_hit<BEHIND>(rec, src, un);
+                }
+                // (the polygons and cylinders a ray is left with go to the wave's queue of tests, as in the walk lane by lane)
+                if (pass) hl.template push_item<1>(S, i, src, ray, near, ignore, ctr);
             } else {
-                if (live && bound_may_hit<BEHIND>(rec, src, un)) cone_item<true>(S, i, src, ray, near, ignore, hl, ctr);
+                if (live && bound_may_hit<BEHIND>(rec, src, un)) hl.template push_item<2>(S, i, src, ray, near, ignore, ctr);
             }
         }
     }
+    if (queued_kind == 1u) hl.template flush<1>(S, src, ray, near, ignore, ctr);
+    if (queued_kind == 2u) hl.template flush<2>(S, src, ray, near, ignore, ctr);
     return true;
 }
 
@@ -1476,7 +1589,7 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     bool beamed = false;
     if constexpr (BEAM != 0)
         beamed = beam_runs<BEAM == 2, MODE == 2>(S, src, ray, unit_ray(ray, tame ? a : 1.0f), a, near, ignore, tame, tame && in_root, hl, ctr,
-                                                 lane_words, stride, apex, limit, BEAM == 3 ? (uint32_t)RT_BEAM_MOST : WQ_CAP);
+                                                 lane_words, stride, apex, limit, BEAM == 3 ? (uint32_t)RT_BEAM_MOST : WQ_CAP, ri);
     if constexpr (BEAM == 3) {
         if (!beamed) return in_root && kd_traverse_closest<MODE, Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
     }
