@@ -811,6 +811,7 @@ struct KdWalk {
     static constexpr int MODE = CULL & 3;
     static constexpr bool OCCL = OCC != 0;
     static constexpr int BND = LEAN ? 0 : MODE;  // (a lean scene has no cones and next to no polygons)
+    static constexpr bool POLY = (CULL & 512) == 0;  // (+ 512: no leaf of the scene has a polygon run with bounding records, and the kernel carries no code for one)
     const DevScene& S;
     Ctr& ctr;
     F3 src, ray, un;
@@ -918,9 +919,11 @@ struct KdWalk {
                 }
                 RT_PHASE(1);  // sphere hierarchy
                 if constexpr (!LEAN) {
-                    if (q3.w != 0xffffffffu && tame && !occ.decided(st, lb)) {  // polygon run with bounding records
-                        leaf_run_lane<1, MODE == 2, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec, ri);
-                        q3.y = 0u;
+                    if constexpr (POLY) {
+                        if (q3.w != 0xffffffffu && tame && !occ.decided(st, lb)) {  // polygon run with bounding records
+                            leaf_run_lane<1, MODE == 2, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, lb, ctr, lane_words, stride, occ, st, lrec, ri);
+                            q3.y = 0u;
+                        }
                     }
                     RT_PHASE(2);  // polygon hierarchy
                     if (cyl_n != 0u && tame && near >= 0.0f && !occ.decided(st, lb)) {  // cylinder run with bounding records
@@ -1376,10 +1379,10 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
 // TO_APEX false: the rays start at one point (camera rays).  TO_APEX true: they all make for `apex` (shadow rays and
 // their light: a ray's direction is fl(fl(apex - src) / its length), which points at the apex to 3u, and `limit` is
 // that length), from origins of their own; what a ray can hit lies between its origin and the apex, or beyond the apex.
-template <bool TO_APEX, bool BEHIND, class LB, class Ctr>
+template <bool TO_APEX, bool BEHIND, bool POLY, class LB, class Ctr>
 RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float near, uint32_t ignore, bool tame, bool live,
                       LB& hl, Ctr& ctr, uint32_t* lane_words, uint32_t stride, F3 apex, float limit, uint32_t most, const RayInv& ri) {
-    constexpr bool BOX = RT_POLY_BOXES != 0;  // polygon runs by their box records
+    constexpr bool BOX = POLY && RT_POLY_BOXES != 0;  // polygon runs by their box records
     if (__ballot(true) != ~0ull) return false;
     const uint32_t lane = hl.lane;
     const uint64_t m_live = __ballot(live);
@@ -1474,7 +1477,9 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
     uint32_t n_cand = 0u;
     const uint4 q2 = S.all_q2, q3 = S.all_q3;
     if (q2.y >= CULL_MIN_SPHERES && !beam_collect<0, false>(S, b, q2.x, q2.y, q3.z, ww, stride, n_cand, lane, ctr)) return false;
-    if (q3.w != 0xffffffffu && !beam_collect<1, BOX>(S, b, q3.x, q3.y, q3.w, ww, stride, n_cand, lane, ctr)) return false;
+    if constexpr (POLY) {
+        if (q3.w != 0xffffffffu && !beam_collect<1, BOX>(S, b, q3.x, q3.y, q3.w, ww, stride, n_cand, lane, ctr)) return false;
+    }
     if (S.all_w != 0xffffffffu) {
         const uint32_t cyl_n = __float_as_uint(ld_f4<true>(S.bnd, S.all_w).w) >> 3;
         if (!beam_collect<2, false>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, n_cand, lane, ctr)) return false;
@@ -1516,9 +1521,11 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
         }
         for (uint32_t j = 0u; j < n; ++j) {
             const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
-            if ((e >> 30) == 2u && queued_kind == 1u) {  // (the candidates come kind by kind: the queue holds one kind at a time)
-                hl.template flush<1>(S, src, ray, near, ignore, ctr);
-                queued_kind = 0u;
+            if constexpr (POLY) {
+                if ((e >> 30) == 2u && queued_kind == 1u) {  // (the candidates come kind by kind: the queue holds one kind at a time)
+                    hl.template flush<1>(S, src, ray, near, ignore, ctr);
+                    queued_kind = 0u;
+                }
             }
             if ((e >> 30) != 0u) queued_kind = e >> 30;
             const float4 rec = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_rec.x), (int)j)),
@@ -1538,7 +1545,7 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
             if (kind == 0u) {
                 float d, c;
                 if (live && sphere_quick(rec.x, rec.y, rec.z, rec.w, src, ray, a, d, c)) sphere_finish<true>(S, i, d, c, a, near, ignore, hl, ctr);
-            } else if (kind == 1u) {
+            } else if (POLY && kind == 1u) {
                 bool pass = live;
                 if constexpr (BOX) {
                     const float4 hi = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_hi.x), (int)j)),
@@ -1555,7 +1562,9 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
             }
         }
     }
-    if (queued_kind == 1u) hl.template flush<1>(S, src, ray, near, ignore, ctr);
+    if constexpr (POLY) {
+        if (queued_kind == 1u) hl.template flush<1>(S, src, ray, near, ignore, ctr);
+    }
     if (queued_kind == 2u) hl.template flush<2>(S, src, ray, near, ignore, ctr);
     return true;
 }
@@ -1565,7 +1574,8 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
 // BEAM: step (A) by beam_runs where it can be; 1: the rays of a wave leave one point (camera rays), 2: they make for one
 // point, `apex` (shadow rays); 3: as 1, for trees that partition well: only with at most RT_BEAM_MOST candidates, and a
 // wave it is not done for is walked leaf by leaf (KdWalk), which there costs less than finding all of a ray's hits.
-template <int MODE, bool SHADOW, class Ctr, int BEAM = 0>
+// POLY false: no polygon run with bounding records anywhere in the scene, and no code for one.
+template <int MODE, bool SHADOW, class Ctr, int BEAM = 0, bool POLY = true>
 RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out, uint2* stack,
                              Ctr& ctr, float limit, F3 apex = F3{0.0f, 0.0f, 0.0f}) {
     static_assert(MODE == 1 || MODE == 2, "the hit-list walk goes by the bounding records");
@@ -1588,10 +1598,10 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     RT_HITSTAT(0, 1u);
     bool beamed = false;
     if constexpr (BEAM != 0)
-        beamed = beam_runs<BEAM == 2, MODE == 2>(S, src, ray, unit_ray(ray, tame ? a : 1.0f), a, near, ignore, tame, tame && in_root, hl, ctr,
+        beamed = beam_runs<BEAM == 2, MODE == 2, POLY>(S, src, ray, unit_ray(ray, tame ? a : 1.0f), a, near, ignore, tame, tame && in_root, hl, ctr,
                                                  lane_words, stride, apex, limit, BEAM == 3 ? (uint32_t)RT_BEAM_MOST : WQ_CAP, ri);
     if constexpr (BEAM == 3) {
-        if (!beamed) return in_root && kd_traverse_closest<MODE, Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        if (!beamed) return in_root && kd_traverse_closest<MODE | (POLY ? 0 : 512), Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
     }
     if (tame && in_root) {  // ---- (A)  the walk of a leaf (KdWalk::round), of the leaf that lists every primitive
         constexpr bool BEHIND = MODE == 2;
@@ -1608,10 +1618,12 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
             q2.y = 0u;
         }
         RT_PHASE(1);
-        if (q3.w != 0xffffffffu) {  // polygons
-            leaf_run_lane<1, BEHIND, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec, ri);
-            hl.template flush<1>(S, src, ray, near, ignore, ctr);
-            q3.y = 0u;
+        if constexpr (POLY) {
+            if (q3.w != 0xffffffffu) {  // polygons
+                leaf_run_lane<1, BEHIND, false>(S, q3.x, q3.y, q3.w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec, ri);
+                hl.template flush<1>(S, src, ray, near, ignore, ctr);
+                q3.y = 0u;
+            }
         }
         RT_PHASE(2);
         if (S.all_w != 0xffffffffu) {  // cylinders (the cone items before q2.z)
@@ -1634,7 +1646,7 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     RT_HITSTAT(2, n_hits);
     if (!tame || n_hits > HIT_CAP) {  // (rare)
         RT_HITSTAT(1, 1u);
-        if (in_root) r_hit = kd_traverse_closest<MODE, Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        if (in_root) r_hit = kd_traverse_closest<MODE | (POLY ? 0 : 512), Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
         return r_hit;
     }
     uint32_t mask = (1u << n_hits) - 1u;
@@ -1750,7 +1762,7 @@ template <int CULL, class Ctr, int OCC>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr, float limit) {
     if constexpr ((CULL & 64) != 0) {  // (+ 64: the hit-list walk)
-        return kd_traverse_hits<CULL & 3, false, Ctr, (CULL & 128) == 0 ? 0 : ((CULL & 256) != 0 ? 3 : 1)>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        return kd_traverse_hits<CULL & 3, false, Ctr, (CULL & 128) == 0 ? 0 : ((CULL & 256) != 0 ? 3 : 1), (CULL & 512) == 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
     } else {
         KdDeep<(CULL & 4) == 0> deep;
         KdWalk<CULL, Ctr, OCC> w(S, stack, ctr, deep);
