@@ -181,7 +181,7 @@ def polygon_cloud(rng, n, scale, offset):
 
 @pytest.mark.parametrize("scale,offset", [(1.0, (0.0, 0.0, 0.0)), (1.0, (1000.0, 1000.0, 500.0)), (1e-3, (0.5, 0.25, -0.125))])
 def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offset):
-    """Big polygon leaves skip groups of polygons through the spheres that stand in for them.
+    """Big polygon leaves skip groups of polygons through the spheres and the boxes that stand in for them.
     Same bar as for spheres: primitive, distance bits and normal bits of the culled walk equal the
     exhaustive walk and the oracle, for rays through vertices and along edges (to a few ulps),
     rays almost inside a polygon's plane, origins on polygons and far away, unnormalised rays."""
@@ -213,13 +213,21 @@ def test_polygon_culling_never_changes_a_hit(rtamd, oracle, gpu_ctx, scale, offs
     start = rng.integers(0, len(polys), n)
     on = rng.random(n) < 0.2      # origins on another polygon (as reflection and shadow rays have)
     src = np.where(on[:, None], np.stack([polys[k].astype(np.float64).mean(0) for k in start]), src)
+    # rays along a coordinate axis or a coordinate plane, exactly (a zero component: the box records' slab test is
+    # not for them, they keep the spheres) and all but (a component of 1e-12 of the others: quotients of 1e12 and more)
+    flat = rng.random(n) < 0.12
+    ax = rng.integers(0, 3, n)
+    src = np.where(flat[:, None] & (np.arange(3)[None, :] == ax[:, None]), tgt, src)  # (the origin level with the target)
     d = tgt - src
     d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-300)
+    tiny = rng.choice([0.0, 1e-12, -1e-12, 3e-7], n)
+    d = np.where(flat[:, None] & (np.arange(3)[None, :] == ax[:, None]), tiny[:, None], d)
     d *= rng.choice([1.0, 1.0, 0.01, 250.0], n)[:, None]
     src, d = src.astype(np.float32), d.astype(np.float32)
     near = rng.choice(np.array([0.0, 0.0, 1e-4, -0.25], np.float32) * np.float32(scale), n).astype(np.float32)
     ignore = np.where(rng.random(n) < 0.3, np.where(on, start, pick) + 1, 0xFFFFFFFF).astype(np.uint32)
     wp, wd, wn = o.intersect_rays(src, d, near, ignore)
+    assert SEED_SHIFT or (wp[flat] != 0xFFFFFFFF).mean() > 0.2
     ep, ed, en = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT | rtamd.DEBUG_EXHAUSTIVE)
     gp, gd, gn = sc.debug_intersect(src, d, near, ignore, rtamd.FP_EXACT)
     assert np.array_equal(ep, wp) and np.array_equal(bits(ed), bits(wd)) and np.array_equal(bits(en), bits(wn))
