@@ -1236,6 +1236,9 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
 // every lane walks the records for itself as before (nothing has been tested by then).
 // ---------------------------------------------------------------------------------------
 constexpr float BEAM_BETA = 3e-5f;
+#ifndef RT_BEAM_PLATES
+#define RT_BEAM_PLATES 1
+#endif
 #ifndef RT_BEAM_MOST
 #define RT_BEAM_MOST 256           // camera rays of trees that partition well: most candidates a wave takes to its rays
 #endif
@@ -1281,6 +1284,51 @@ struct Beam {
         const float m = __builtin_fmaf(fmaxf(fabsf(enter), fabsf(leave)), 2e-6f, 1e-30f);
         if (towards) return !(enter - leave > m) && !(enter > 1.00001f);
         return !(enter - leave > m) && !(leave < -m);  // (a NaN, an infinite box: kept)
+    }
+    // Rays from one point against ONE polygon.  The reference accepts the polygon for a ray only at a point X = src +
+    // ray t, t >= 0 the distance it computed, whose two edge-loop coordinates lie in the polygon's extent (what
+    // polygon_rect holds, up to the rounding of fl(src + ray t)) and which lies within u |N| (5 |v0 - src| + 3 |X - src|)
+    // of the plane in (X - v0) . N, N the plane's normal as polygon_plane forms it -- whatever the angle between
+    // ray and plane (leaf_cluster.cpp, polygon_bound).  That is a thin plate: the extent's rectangle, lifted to the
+    // plane along the dropped axis -- the one where |N| is largest -- and as thick as that residue.  Seen from the apex
+    // in coordinates ((X - apex) . e1, (X - apex) . e2) / ((X - apex) . g), which are the same all along a ray and map what
+    // is convex and in front of the apex to what is convex, the rays are a rectangle [u0, u1] x [v0, v1] (their own
+    // coordinates, smallest and largest over the wave) and the plate lies inside the bounds of its eight corners: where
+    // the two do not overlap no ray of the wave meets the plate.  Every widening is generous (1e-5 where a few u are
+    // due), and a plate with a corner not clearly in front of the apex is kept.
+    F3 e1, e2;
+    float u0, u1, v0, v1;
+    RT_DEV bool plate_may_hit(F3 p0, float4 plane, float4 rect) const {
+        const uint32_t minor = __float_as_uint(plane.w) & 3u, major = __float_as_uint(plane.w) >> 2, drop = 3u - minor - major;
+        const F3 N = f3(plane.x, plane.y, plane.z);
+        const float nd = comp(N, drop), nm = comp(N, minor), nM = comp(N, major);
+        if (!(fabsf(nd) > 0.0f) || !(rect.y - rect.x < 1e30f) || !(rect.w - rect.z < 1e30f)) return true;
+        const float reach1 = fabsf(p0.x - apex.x) + fabsf(p0.y - apex.y) + fabsf(p0.z - apex.z) + 4.0f * ((rect.y - rect.x) + (rect.w - rect.z));
+        const float size = reach1 + fabsf(apex.x) + fabsf(apex.y) + fabsf(apex.z);
+        const float wide = 1e-6f * size;   // the extent: 2u (|src| + |X - src|) of fl(src + ray t)
+        const float thick = 1e-5f * size;  // the residue over |N_drop| (|N| <= sqrt(3) |N_drop|), and this function's own roundings
+        const float rm = nm / nd, rM = nM / nd;
+        float lo_u = INFINITY, hi_u = -INFINITY, lo_v = INFINITY, hi_v = -INFINITY;
+        bool front = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float a = (k & 1) ? rect.y + wide : rect.x - wide, b = (k & 2) ? rect.w + wide : rect.z - wide;
+            const float lift = rm * (a - comp(p0, minor)) + rM * (b - comp(p0, major));
+            const float z = comp(p0, drop) - lift + ((k & 4) ? thick : -thick) * (1.0f + fabsf(rm) + fabsf(rM));
+            F3 q;
+            q.x = (minor == 0u ? a : (major == 0u ? b : z)) - apex.x;
+            q.y = (minor == 1u ? a : (major == 1u ? b : z)) - apex.y;
+            q.z = (minor == 2u ? a : (major == 2u ? b : z)) - apex.z;
+            const float w = dot(q, axis);
+            front = front && w > 1e-3f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z));
+            const float iw = 1.0f / w;
+            const float pu = dot(q, e1) * iw, pv = dot(q, e2) * iw;
+            lo_u = fminf(lo_u, pu); hi_u = fmaxf(hi_u, pu);
+            lo_v = fminf(lo_v, pv); hi_v = fmaxf(hi_v, pv);
+        }
+        if (!front) return true;
+        const float su = 1e-5f * (1.0f + fmaxf(fabsf(lo_u), fabsf(hi_u))), sv = 1e-5f * (1.0f + fmaxf(fabsf(lo_v), fabsf(hi_v)));
+        return !(lo_u - su > u1 || hi_u + su < u0 || lo_v - sv > v1 || hi_v + sv < v0);  // (a NaN keeps)
     }
     RT_DEV bool may_hit(float cx, float cy, float cz, float q) const {
         const float dx = cx - apex.x, dy = cy - apex.y, dz = cz - apex.z;
@@ -1351,7 +1399,13 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
                 rec = (KIND == 1 ? S.poly_bound : S.cone_bound)[first + i];
             }
         }
-        const bool pass = mine && (BOX ? b.box_may_hit(rec, rec_hi, box_w) : b.may_hit(rec.x, rec.y, rec.z, rec.w));
+        bool pass = mine && (BOX ? b.box_may_hit(rec, rec_hi, box_w) : b.may_hit(rec.x, rec.y, rec.z, rec.w));
+        if constexpr (BOX && KIND == 1 && RT_BEAM_PLATES != 0) {
+            if (pass && L == 0u && !b.towards) {  // (a polygon whose box the rays' cone meets: does it meet the polygon's plate?)
+                const uint32_t item = first + i;
+                pass = b.plate_may_hit(from4(S.poly_rec[item * 4u + 3u]), S.poly_rec[item * 4u + 1u], S.poly_rec[item * 4u + 2u]);
+            }
+        }
         if (mine) ctr.bound_tests(1);
         if (lane == 0u) ctr.lane_slots(64);
         const uint64_t m_entry = __ballot(pass && L == 0u), m_inner = __ballot(pass && L != 0u);
@@ -1446,6 +1500,23 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
         return false;
     }
     b.cos_lo = __builtin_amdgcn_sqrtf(1.0f - b.sin_hi * b.sin_hi) * 0.999999f;
+    if constexpr (BOX && !TO_APEX) {
+        // a frame about the axis, and the rays' rectangle in it (plate_may_hit)
+        const F3 g = b.axis;
+        const F3 pick = (fabsf(g.x) <= fabsf(g.y) && fabsf(g.x) <= fabsf(g.z)) ? f3(1.0f, 0.0f, 0.0f)
+                                                                             : (fabsf(g.y) <= fabsf(g.z) ? f3(0.0f, 1.0f, 0.0f) : f3(0.0f, 0.0f, 1.0f));
+        b.e1 = cross(g, pick);
+        b.e2 = cross(g, b.e1);
+        const float iw = 1.0f / dot(ray, g);  // (> 0 for every live lane: within a right angle of the first ray)
+        const float pu = dot(ray, b.e1) * iw, pv = dot(ray, b.e2) * iw;
+        float lo_u = live ? pu : INFINITY, hi_u = live ? pu : -INFINITY, lo_v = live ? pv : INFINITY, hi_v = live ? pv : -INFINITY;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo_u = fminf(lo_u, __shfl_xor(lo_u, off, 64)); hi_u = fmaxf(hi_u, __shfl_xor(hi_u, off, 64));
+            lo_v = fminf(lo_v, __shfl_xor(lo_v, off, 64)); hi_v = fmaxf(hi_v, __shfl_xor(hi_v, off, 64));
+        }
+        const float su = 1e-5f * (1.0f + fmaxf(fabsf(lo_u), fabsf(hi_u))), sv = 1e-5f * (1.0f + fmaxf(fabsf(lo_v), fabsf(hi_v)));
+        b.u0 = lo_u - su; b.u1 = hi_u + su; b.v0 = lo_v - sv; b.v1 = hi_v + sv;
+    }
     if constexpr (BOX) {
         // the rays' direction components, smallest and largest over the wave; their reciprocals' range
         float lo[3], hi[3];

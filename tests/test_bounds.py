@@ -177,6 +177,64 @@ def test_polygon_stand_in_box_holds_every_accepted_point(oracle):
     print("accepted points reach %.3f of the widening the rays are given" % worst)
 
 
+def test_polygon_plate_holds_every_accepted_point(oracle):
+    """What the tile walk's plate test is built on (rt_traverse.h, Beam::plate_may_hit): an accepted point X = src +
+    ray t lies within the polygon's extent on the two edge-loop coordinates, widened by 1e-6 of the coordinates' size
+    (polygon_rect) and by 1e-6 (|src|_1 + reach) more, and within 1e-5 (|src|_1 + reach) |N_drop| of the plane in
+    (X - v0) . N -- also for rays almost inside the plane, whose computed distance is far from the exact one."""
+    rng = np.random.default_rng(26)
+    worst_rect, worst_plane, accepted = 0.0, 0.0, 0
+    for k in range(240):
+        nv = 3 if k % 3 else 4
+        size = 10.0 ** rng.uniform(-2, 1)
+        centre = rng.normal(size=3) * 10.0 ** rng.uniform(-1, 2)
+        v = centre + rng.normal(size=(nv, 3)) * size
+        if k % 5 == 1:
+            v[2] = v[0] + (v[1] - v[0]) * rng.uniform(0.2, 0.8) + rng.normal(size=3) * size * 1e-6
+        elif k % 5 == 2:
+            v[:, rng.integers(0, 3)] = centre[rng.integers(0, 3)]
+        v = v.astype(np.float32)
+        verts6 = np.concatenate([v, np.tile(np.array([[0, 0, 1]], np.float32), (nv, 1))], axis=1)
+        ea, eb = v[1] - v[0], v[2] - v[0]
+        gn = np.array([ea[1] * eb[2] - ea[2] * eb[1], ea[2] * eb[0] - ea[0] * eb[2], ea[0] * eb[1] - ea[1] * eb[0]], np.float32)
+        if abs(gn[2]) > abs(gn[0]) and abs(gn[2]) > abs(gn[1]):
+            minor, major = 1, 0
+        elif abs(gn[1]) > abs(gn[0]):
+            minor, major = 2, 0
+        else:
+            minor, major = 2, 1
+        drop = 3 - minor - major
+        if gn[drop] == 0:
+            continue
+        n = 3000
+        wts = rng.dirichlet(np.ones(nv), n)
+        tgt = wts @ v.astype(np.float64)
+        far = 10.0 ** rng.uniform(-1, 4, (n, 1)) * size
+        d = rng.normal(size=(n, 3))
+        inpl = (v[1].astype(np.float64) - v[0])[None, :] + rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-8, -1, (n, 1)) * size
+        d = np.where(rng.random((n, 1)) < 0.5, inpl, d)  # half of them almost inside the plane
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        src = (tgt - d * far).astype(np.float32)
+        ray = (d * rng.choice([1.0, 0.03, 40.0], (n, 1))).astype(np.float32)
+        hit, x = accepted_points(oracle, KIND_POLYGON, None, verts6, src, ray, np.zeros(n, np.float32))
+        if not hit.any():
+            continue
+        x, s = x[hit], src[hit].astype(np.float64)
+        v64, g64 = v.astype(np.float64), gn.astype(np.float64)
+        ext = (v64[:, minor].max() - v64[:, minor].min()) + (v64[:, major].max() - v64[:, major].min())
+        sz = np.abs(v64[0] - s).sum(1) + 4 * ext + np.abs(s).sum(1)
+        for ax in (minor, major):
+            widen = max(np.abs(v64[:, ax]).max() * 1e-6, 1e-30) + 1e-6 * sz
+            out = np.maximum(v64[:, ax].min() - x[:, ax], x[:, ax] - v64[:, ax].max())
+            worst_rect = max(worst_rect, float((out / widen).max()))
+        off = np.abs((x - v64[0]) @ g64) / abs(g64[drop])
+        worst_plane = max(worst_plane, float((off / (1e-5 * sz)).max()))
+        accepted += int(hit.sum())
+    assert accepted > 20000
+    assert worst_rect <= 1.0 and worst_plane <= 1.0, (worst_rect, worst_plane)
+    print("accepted points reach %.3f of the extent's widening and %.3f of the plate's thickness" % (worst_rect, worst_plane))
+
+
 def test_sphere_acceptance_margin_of_the_bounding_records(oracle):
     """What the sphere records are built on: the reference accepts a sphere only for a line
     within r (1 + 3u) + sqrt(19u) |src - c| of its centre (leaf_cluster.cpp)."""

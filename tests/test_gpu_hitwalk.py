@@ -126,7 +126,7 @@ def test_rays_the_bounding_records_cannot_take(rtamd, oracle, spd, gpu_ctx):
         assert np.array_equal(gp, wp) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(bits(gn), bits(wn)), flags
 
 
-@pytest.mark.parametrize("case", ("lathe", "rings", "wide", "ragged", "inside", "near"))
+@pytest.mark.parametrize("case", ("lathe", "rings", "wide", "ragged", "inside", "near", "graze", "inplane", "among", "tetra"))
 def test_camera_rays_a_tile_at_a_time(rtamd, oracle, spd, gpu_ctx, case):
     """The 64 camera rays of a tile leave one point; the records none of them can pass are ruled out once for all of
     them (a cone about the tile's rays), the entries left are taken to every ray.  Views that strain the cone: a
@@ -135,8 +135,24 @@ def test_camera_rays_a_tile_at_a_time(rtamd, oracle, spd, gpu_ctx, case):
     touches a primitive.  Default options time the first two frames of a kind, one each way, and keep the faster:
     whichever runs, the frame is the oracle's."""
     w, h, depth = 160, 120, 4
-    if case == "lathe":
+    if case in ("lathe", "graze", "inplane", "among"):
+        # graze: the eye a hair above the checker floor (256 quads in the plane z = 0), looking along it; inplane: the
+        # eye IN that plane; among: the eye inside the pot, patches all round and behind it (the plate of a polygon
+        # the rays' cone is tested against has corners behind the eye there)
         text = spd.lathe(nu=32, nv=16, width=w, height=h)
+        eye = {"graze": "from 5.5 0.3 0.0004", "inplane": "from 5.5 0.3 0", "among": "from 0.1 0.05 0.7"}.get(case)
+        if eye:
+            lines = text.split("\n")
+            for k, l in enumerate(lines):
+                if l.startswith("from"):
+                    lines[k] = eye
+                if l.startswith("at") and case != "among":
+                    lines[k] = "at 0 0 0.05"
+                if l.startswith("hither"):
+                    lines[k] = "hither 0.001"
+            text = "\n".join(lines)
+    elif case == "tetra":
+        text = spd.tetra(4, w, h)
     else:
         text = spd.rings(2, w, h)
     if case == "wide":
