@@ -1236,6 +1236,9 @@ RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, u
 // every lane walks the records for itself as before (nothing has been tested by then).
 // ---------------------------------------------------------------------------------------
 constexpr float BEAM_BETA = 3e-5f;
+#ifndef RT_BEAM_START
+#define RT_BEAM_START 256
+#endif
 #ifndef RT_BEAM_PLATES
 #define RT_BEAM_PLATES 1
 #endif
@@ -1374,9 +1377,13 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
     auto level_off = [&](uint32_t L) { return L == 1u ? off1 : (L == 2u ? off2 : (L == 3u ? off3 : (L == 4u ? off4 : off5))); };
     auto level_n = [&](uint32_t L) { return L == 0u ? count : (L == 1u ? n1 : (L == 2u ? n2 : (L == 3u ? n3 : (L == 4u ? n4 : n5)))); };
     auto word = [&](uint32_t j) -> uint32_t& { return ww[(j >> 6) * stride + (j & 63u)]; };
-    const uint32_t n_top = level_n(top);
+    // (from the lowest level of at most RT_BEAM_START records: a few steps of 64 records each that wait for nothing,
+    // instead of one step per level above it with a handful of lanes at work)
+    uint32_t start = top;
+    while (start > 1u && level_n(start - 1u) <= (uint32_t)RT_BEAM_START) --start;
+    const uint32_t n_top = level_n(start);
     if (n_top + n_cand > BEAM_PENDING) return false;
-    for (uint32_t i = lane; i < n_top; i += 64u) word(i) = (top << 28) | i;
+    for (uint32_t i = lane; i < n_top; i += 64u) word(i) = (start << 28) | i;
     uint32_t size = n_top;
     while (size != 0u) {
         const uint32_t n = size < 64u ? size : 64u;
