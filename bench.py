@@ -119,7 +119,7 @@ def parse_args():
     ap.add_argument("--cpu-rows", type=int, default=32, help="rows of the frame the CPU baseline renders per leg")
     ap.add_argument("--lights", type=int, default=0, help="mount only: number of point lights")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--in-flight", default="auto", help="frames kept queued: a number, or auto = measured (2 or 4) before the warmup")
+    ap.add_argument("--in-flight", default="auto", help="frames kept queued: a number, or auto = measured (1, 2 or 4) before the warmup")
     ap.add_argument("--serial", action="store_true",
                     help="timed frames one at a time on the serial schedule (one stream, one shadow launch): what the "
                          "per-kernel profiles under profiles/ are taken with")
@@ -172,7 +172,7 @@ def main():
     else:
         image = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
 
-    # Frames are queued without waiting for the previous one (two or four in flight, whichever measured faster): the small
+    # Frames are queued without waiting for the previous one (one, two or four in flight, whichever measured fastest): the small
     # launches that end a frame run beside the big ones that start the next.  Each frame's image
     # is complete, in HBM, before the next frame may write the buffer (stream order).
     pending, stats = [], []
@@ -201,7 +201,7 @@ def main():
     if args.serial:
         in_flight[0] = 1
     elif args.in_flight == "auto":
-        cand = [c for c in (2, 4) if c <= ctx.frames_in_flight]
+        cand = [c for c in (1, 2, 4) if c <= ctx.frames_in_flight]  # (1: frames of tens of milliseconds whose resident blocks fill the device gain nothing from a second one)
         took = []
         for c in cand:
             in_flight[0] = c
