@@ -420,7 +420,7 @@ def main():
             # vector issue with few waves ready per SIMD does.  The HBM view is alongside.
             "bound": "valu",
             "kernel": k_shadow_name + " (CULL: 2 = culled walk, + 4 lean build, + 8 resident blocks, + 16 nodes in LDS, + 64 hit-list walk: all of a "
-                      "ray's hits first, then the sub-trees that hold one, + 512 built without the code for polygon runs: the scene has none); "
+                      "ray's hits first, then the sub-trees that hold one, + 512 built without the code for polygon runs, + 1024 without the code for cones and cylinders: the scene has none); "
                       "deeper levels: " + k_deep_name,
             "achieved": round(sh_flops / sh_s / 1e12, 4),
             "peak": PEAK_F32_TFLOPS,

@@ -769,6 +769,7 @@ extern "C" int rt_scene_create(rt_context* ctx, const rt_scene_desc* desc, rt_sc
     d.n_nodes = (uint32_t)sc->tree.nodes.size();
     d.hit_tables = hit_walk ? 1u : 0u;
     d.poly_runs = any_poly_walk ? 1u : 0u;
+    d.cone_count = (uint32_t)sd.cones.size();
     d.hit_walk = (hit_walk && d.lean == 0u) ? 1u : 0u;
     d.hit_walk_level0 = (d.hit_walk != 0u && (uint64_t)sc->tree.info.max_leaf * 4u >= sd.primitives.size()) ? 1u : 0u;
     if (const char* e = getenv("RTAMD_HIT_LEVEL0")) d.hit_walk_level0 = (d.hit_walk != 0u && atoi(e) != 0) ? 1u : 0u;  // (experiment)

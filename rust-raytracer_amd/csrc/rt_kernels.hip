@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
         bool found;
         if constexpr ((CULL & 64) != 0) {
             const float4 lp = S.lights[((CULL & 8) != 0 ? (uint32_t)(i / A.shadow_cap) : blockIdx.y) * 2u];  // (one light's rays per wave)
-            found = kd_traverse_hits<CULL & 3, true, Ctr, (CULL & 128) != 0 ? 2 : 0, (CULL & 512) == 0>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f,
+            found = kd_traverse_hits<CULL & 3, true, Ctr, (CULL & 128) != 0 ? 2 : 0, (CULL & 512) == 0, (CULL & 1024) == 0>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f,
                                                                                    __float_as_uint(sd.w), blocker, lds_stack, ctr, so.w,
                                                                                    f3(lp.x, lp.y, lp.z));
         } else {
@@ -1133,6 +1133,7 @@ static uint32_t g_cus = 256;  // compute units of the device (init_kernels)
 constexpr int GEN_ID = 2 | 8 | 16, GEN_SH = 2 | 8 | 16;
 constexpr int HITS_ID = 2 | 64, HITS_SH = 2 | 64;  // the hit-list walk (DevScene::hit_walk): deeper levels, shadow rays
 constexpr int HITS_SHB = 2 | 64 | 128;        // shadow rays of scenes of polygons (DevScene::beam_shadow): 64 at a time towards their light where they lie together (beam_runs)
+constexpr int NOCONE = 1024;  // + 1024: kernels for scenes without a cone or cylinder (DevScene::cone_count == 0): no code for one
 constexpr int NOPOLY = 512;  // + 512: kernels for scenes without a polygon run with bounding records (DevScene::poly_runs == 0): no code for one
 constexpr int HITS_I0L = 1 | 64 | 128 | 256;  // camera rays of the other scenes with the hit-list tables: by the wave where that is cheap, else leaf by leaf
 constexpr int HITS_I0 = 1 | 64 | (RT_BEAM ? 128 : 0);  // ... and camera rays (+ 128: a wave's rays leave one point, beam_runs)
@@ -1210,11 +1211,13 @@ hipError_t init_kernels() {
                          (const void*)k_deep<HITS_ID, NoCounters>,
                          (const void*)k_intersect<false, HITS_ID | NOPOLY, NoCounters>, (const void*)k_shadow<HITS_SH | NOPOLY, NoCounters>,
                          (const void*)k_deep<HITS_ID | NOPOLY, NoCounters>,
+                         (const void*)k_intersect<false, HITS_ID | NOCONE, NoCounters>, (const void*)k_shadow<HITS_SH | NOCONE, NoCounters>,
+                         (const void*)k_deep<HITS_ID | NOCONE, NoCounters>,
 #if RT_HITS_LEVEL0
-                         (const void*)k_intersect<true, HITS_I0 | NOPOLY, NoCounters>,
+                         (const void*)k_intersect<true, HITS_I0 | NOPOLY, NoCounters>, (const void*)k_intersect<true, HITS_I0 | NOCONE, NoCounters>,
 #endif
 #if RT_BEAM
-                         (const void*)k_intersect<true, HITS_I0L | NOPOLY, NoCounters>,
+                         (const void*)k_intersect<true, HITS_I0L | NOPOLY, NoCounters>, (const void*)k_intersect<true, HITS_I0L | NOCONE, NoCounters>,
 #endif
                          (const void*)k_debug_intersect<0>, (const void*)k_debug_intersect<2>, (const void*)k_debug_intersect<HITS_ID>};
     for (const void* f : fns) {
@@ -1279,20 +1282,24 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
     const dim3 g(blocks_of(grid, tb, stays, gen_stays ? 1u : RT_LEAN_BLOCKS_PER_CU)), b(tb);
     const size_t lds = stack_bytes(A.scene, !work && cull && lean && !beam_or_leaf, tb, stays, hit_walk);
     const bool nopoly = !work && hit_walk && A.scene.poly_runs == 0u;
+    const bool nocone = !work && hit_walk && !nopoly && A.scene.cone_count == 0u;  // (a scene has polygon runs, or cones, or both)
     if (variant) {
         if (level == 0) *variant = !cull ? 0 : (beam_or_leaf ? HITS_I0L : (hit_walk ? HITS_I0 : (!work && lean ? LEAN_I0 : 1)));
         else *variant = !cull ? 0 : (hit_walk ? HITS_ID : (work ? 2 : (lean ? LEAN_ID : (gen_stays ? GEN_ID : 2))));
         if (nopoly) *variant |= NOPOLY;
+        if (nocone) *variant |= NOCONE;
     }
     if (level == 0) {  // camera rays start outside the scene: the line test alone
 #if RT_BEAM
         if (beam_or_leaf && nopoly) hipLaunchKernelGGL((k_intersect<true, HITS_I0L | NOPOLY, NoCounters>), g, b, lds, st, A, level);
+        else if (beam_or_leaf && nocone) hipLaunchKernelGGL((k_intersect<true, HITS_I0L | NOCONE, NoCounters>), g, b, lds, st, A, level);
         else if (beam_or_leaf) hipLaunchKernelGGL((k_intersect<true, HITS_I0L, NoCounters>), g, b, lds, st, A, level);
         else
 #endif
 #if RT_HITS_LEVEL0
         if (work && hit_walk) hipLaunchKernelGGL((k_intersect<true, HITS_I0, WorkCounters>), g, b, lds, st, A, level);
         else if (hit_walk && nopoly) hipLaunchKernelGGL((k_intersect<true, HITS_I0 | NOPOLY, NoCounters>), g, b, lds, st, A, level);
+        else if (hit_walk && nocone) hipLaunchKernelGGL((k_intersect<true, HITS_I0 | NOCONE, NoCounters>), g, b, lds, st, A, level);
         else if (hit_walk) hipLaunchKernelGGL((k_intersect<true, HITS_I0, NoCounters>), g, b, lds, st, A, level);
         else
 #endif
@@ -1304,6 +1311,7 @@ hipError_t launch_intersect(const FrameArgs& A, uint32_t level, bool work, bool 
     } else {
         if (work && hit_walk) hipLaunchKernelGGL((k_intersect<false, HITS_ID, WorkCounters>), g, b, lds, st, A, level);
         else if (hit_walk && nopoly) hipLaunchKernelGGL((k_intersect<false, HITS_ID | NOPOLY, NoCounters>), g, b, lds, st, A, level);
+        else if (hit_walk && nocone) hipLaunchKernelGGL((k_intersect<false, HITS_ID | NOCONE, NoCounters>), g, b, lds, st, A, level);
         else if (hit_walk) hipLaunchKernelGGL((k_intersect<false, HITS_ID, NoCounters>), g, b, lds, st, A, level);
         else if (work && cull) hipLaunchKernelGGL((k_intersect<false, 2, WorkCounters>), g, b, lds, st, A, level);
         else if (work) hipLaunchKernelGGL((k_intersect<false, 0, WorkCounters>), g, b, lds, st, A, level);
@@ -1337,9 +1345,11 @@ hipError_t launch_deep(const FrameArgs& A, uint32_t grid, uint32_t per_cu, hipSt
     const dim3 g(blocks_of(grid, tb, true, per_cu != 0u && per_cu < most ? per_cu : most)), b(tb);
     const size_t lds = stack_bytes(A.scene, lean, tb, lean || lds_nodes, hit_walk);
     const bool nopoly = hit_walk && A.scene.poly_runs == 0u;
-    if (variant) *variant = (lean ? LEAN_ID : (hit_walk ? HITS_ID | (nopoly ? NOPOLY : 0) : (lds_nodes ? GEN_ID : 2))) + 32;  // (+ 32: all deeper levels in one launch)
+    const bool nocone = hit_walk && !nopoly && A.scene.cone_count == 0u;
+    if (variant) *variant = (lean ? LEAN_ID : (hit_walk ? HITS_ID | (nopoly ? NOPOLY : 0) | (nocone ? NOCONE : 0) : (lds_nodes ? GEN_ID : 2))) + 32;  // (+ 32: all deeper levels in one launch)
     if (lean) hipLaunchKernelGGL((k_deep<LEAN_ID, NoCounters>), g, b, lds, st, A);
     else if (nopoly) hipLaunchKernelGGL((k_deep<HITS_ID | NOPOLY, NoCounters>), g, b, lds, st, A);
+    else if (nocone) hipLaunchKernelGGL((k_deep<HITS_ID | NOCONE, NoCounters>), g, b, lds, st, A);
     else if (hit_walk) hipLaunchKernelGGL((k_deep<HITS_ID, NoCounters>), g, b, lds, st, A);
     else if (lds_nodes) hipLaunchKernelGGL((k_deep<GEN_ID, NoCounters>), g, b, lds, st, A);
     else hipLaunchKernelGGL((k_deep<2, NoCounters>), g, b, lds, st, A);
@@ -1374,7 +1384,7 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
     const bool lean = A.scene.lean != 0;
     const bool beam = RT_BEAM_SHADOW != 0 && hit_walk && !work && A.scene.beam_shadow != 0u;
     if (variant) {
-        if (hit_walk) *variant = beam ? HITS_SHB : (HITS_SH | (!work && A.scene.poly_runs == 0u ? NOPOLY : 0));
+        if (hit_walk) *variant = beam ? HITS_SHB : (HITS_SH | (!work && A.scene.poly_runs == 0u ? NOPOLY : (!work && A.scene.cone_count == 0u ? NOCONE : 0)));
         else if (work || mode == 0) *variant = mode;
         else if (A.shadow_mode == 1 || A.shadow_mode == 2) *variant = lean ? LEAN_SH : 2;
         else *variant = lean ? LEAN_SH : (gen_stays ? GEN_SH : 2);
@@ -1385,6 +1395,7 @@ hipError_t launch_shadow(const FrameArgs& A, uint32_t first_level, uint32_t last
         else if (beam) hipLaunchKernelGGL((k_shadow<HITS_SHB, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
 #endif
         else if (A.scene.poly_runs == 0u) hipLaunchKernelGGL((k_shadow<HITS_SH | NOPOLY, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
+        else if (A.scene.cone_count == 0u) hipLaunchKernelGGL((k_shadow<HITS_SH | NOCONE, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
         else hipLaunchKernelGGL((k_shadow<HITS_SH, NoCounters>), g, b, lds, st, A, first_level, last_level, chunk);
     } else if (work) {
         if (mode == 2) hipLaunchKernelGGL((k_shadow<2, WorkCounters>), g, b, lds, st, A, first_level, last_level, chunk);

@@ -78,6 +78,7 @@ struct DevScene {
                                // (trees of small leaves, where rays differ most in the number of leaves they visit)
     // The hit-list walk (rt_traverse.h, HitWalk): hit_walk != 0 -> the scene has the tables it needs.
     uint32_t hit_walk;         // ... and its deeper levels and shadow rays go that way (never those of a lean scene)
+    uint32_t cone_count;       // cones and cylinders in the scene
     uint32_t poly_runs;        // 1: some leaf (the leaf of all primitives included) has a polygon run with bounding records
     uint32_t beam_shadow;      // 1: a scene of polygons (the leaf of all primitives has a polygon run with records, no long sphere run and
                                // no cylinder run): shadow rays that lie together are taken 64 at a time towards their light (beam_runs)

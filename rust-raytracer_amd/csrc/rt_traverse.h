@@ -714,11 +714,13 @@ RT_DEV void leaf_run_lane(const DevScene& S, uint32_t first, uint32_t count, uin
     drain();
 }
 
-template <bool U, int BND, bool BATCH, class LB, class Ctr>
+template <bool U, int BND, bool BATCH, bool CONE = true, class LB, class Ctr>
 RT_DEV void leaf_runs(const DevScene& S, uint4 q2, uint4 q3, F3 src, F3 ray, F3 un, bool ok_cone, bool ok_poly, float a,
                       float near, uint32_t ignore, LB& lb, Ctr& ctr) {
     if (q2.y) leaf_spheres<U, BATCH>(S, q2.x, q2.y, src, ray, a, near, ignore, lb, ctr);
-    if (q2.w) leaf_cones<U, BND>(S, q2.z, q2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
+    if constexpr (CONE) {
+        if (q2.w) leaf_cones<U, BND>(S, q2.z, q2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
+    }
     if (q3.y) leaf_polygons<U, BND>(S, q3.x, q3.y, src, ray, un, ok_poly, near, ignore, lb, ctr);
 }
 
@@ -811,6 +813,7 @@ struct KdWalk {
     static constexpr int MODE = CULL & 3;
     static constexpr bool OCCL = OCC != 0;
     static constexpr int BND = LEAN ? 0 : MODE;  // (a lean scene has no cones and next to no polygons)
+    static constexpr bool CONE = (CULL & 1024) == 0;  // (+ 1024: the scene has no cone or cylinder at all, and the kernel no code for one)
     static constexpr bool POLY = (CULL & 512) == 0;  // (+ 512: no leaf of the scene has a polygon run with bounding records, and the kernel carries no code for one)
     const DevScene& S;
     Ctr& ctr;
@@ -926,10 +929,12 @@ struct KdWalk {
                         }
                     }
                     RT_PHASE(2);  // polygon hierarchy
-                    if (cyl_n != 0u && tame && near >= 0.0f && !occ.decided(st, lb)) {  // cylinder run with bounding records
-                        leaf_run_lane<2, MODE == 2, false>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, un, a, near, ignore, lb, ctr,
-                                                           lane_words, stride, occ, st, lrec, ri);
-                        cyl_n = 0u;
+                    if constexpr (CONE) {
+                        if (cyl_n != 0u && tame && near >= 0.0f && !occ.decided(st, lb)) {  // cylinder run with bounding records
+                            leaf_run_lane<2, MODE == 2, false>(S, q2.z - cyl_n, cyl_n, leaf_w, src, ray, un, a, near, ignore, lb, ctr,
+                                                               lane_words, stride, occ, st, lrec, ri);
+                            cyl_n = 0u;
+                        }
                     }
                     RT_PHASE(3);  // cylinder hierarchy
                 }
@@ -945,7 +950,7 @@ struct KdWalk {
             // Long lists are walked by all lanes standing on the same leaf together, index
             // wave-uniform (entries arrive by scalar loads); the culling kernels only keep that
             // path for the cone items (cones proper, and cylinders too few for a hierarchy).
-            if constexpr (LEAN) q2.w = 0u;  // (there are no cones)
+            if constexpr (LEAN || !CONE) q2.w = 0u;  // (there are no cones)
             const uint32_t together = MODE != 0 ? q2.w : q2.y + q2.w + q3.y;
             if (together >= BIG_LEAF) {
                 // Lanes walk together only when they stand on the same leaf with the same entries left:
@@ -960,17 +965,18 @@ struct KdWalk {
                                                     __builtin_amdgcn_readfirstlane(q2.z), __builtin_amdgcn_readfirstlane(q2.w));
                         const uint4 u3 = make_uint4(__builtin_amdgcn_readfirstlane(q3.x), __builtin_amdgcn_readfirstlane(q3.y),
                                                     0u, 0u);
-                        if constexpr (MODE != 0) leaf_cones<true, BND>(S, u2.z, u2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
-                        else leaf_runs<true, 0, false>(S, u2, u3, src, ray, un, false, false, a, near, ignore, lb, ctr);
+                        if constexpr (MODE != 0 && CONE) leaf_cones<true, BND>(S, u2.z, u2.w, src, ray, un, ok_cone, near, ignore, lb, ctr);
+                        else if constexpr (MODE != 0) (void)u2;
+                        else leaf_runs<true, 0, false, CONE>(S, u2, u3, src, ray, un, false, false, a, near, ignore, lb, ctr);
                         mine_done = true;
                     }
                 }
                 if constexpr (MODE != 0) {
                     q2.w = 0u;
-                    leaf_runs<false, BND, MODE != 0>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
+                    leaf_runs<false, BND, MODE != 0, CONE>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
                 }
             } else {
-                leaf_runs<false, BND, MODE != 0>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
+                leaf_runs<false, BND, MODE != 0, CONE>(S, q2, q3, src, ray, un, ok_cone, tame, a, near, ignore, lb, ctr);
             }
             RT_PHASE(4);  // short runs, cones proper
             r_hit = lb.have;
@@ -1440,7 +1446,7 @@ RT_DEV bool beam_collect(const DevScene& S, const Beam& b, uint32_t first, uint3
 // TO_APEX false: the rays start at one point (camera rays).  TO_APEX true: they all make for `apex` (shadow rays and
 // their light: a ray's direction is fl(fl(apex - src) / its length), which points at the apex to 3u, and `limit` is
 // that length), from origins of their own; what a ray can hit lies between its origin and the apex, or beyond the apex.
-template <bool TO_APEX, bool BEHIND, bool POLY, class LB, class Ctr>
+template <bool TO_APEX, bool BEHIND, bool POLY, bool CONE, class LB, class Ctr>
 RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float near, uint32_t ignore, bool tame, bool live,
                       LB& hl, Ctr& ctr, uint32_t* lane_words, uint32_t stride, F3 apex, float limit, uint32_t most, const RayInv& ri) {
     constexpr bool BOX = POLY && RT_POLY_BOXES != 0;  // polygon runs by their box records
@@ -1558,9 +1564,11 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
     if constexpr (POLY) {
         if (q3.w != 0xffffffffu && !beam_collect<1, BOX>(S, b, q3.x, q3.y, q3.w, ww, stride, n_cand, lane, ctr)) return false;
     }
-    if (S.all_w != 0xffffffffu) {
-        const uint32_t cyl_n = __float_as_uint(ld_f4<true>(S.bnd, S.all_w).w) >> 3;
-        if (!beam_collect<2, false>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, n_cand, lane, ctr)) return false;
+    if constexpr (CONE) {
+        if (S.all_w != 0xffffffffu) {
+            const uint32_t cyl_n = __float_as_uint(ld_f4<true>(S.bnd, S.all_w).w) >> 3;
+            if (!beam_collect<2, false>(S, b, q2.z - cyl_n, cyl_n, S.all_w, ww, stride, n_cand, lane, ctr)) return false;
+        }
     }
     if (n_cand > most) {  // (the caller has a cheaper way for so many)
         if (lane == 0u) RT_HITSTAT(8, 1u);
@@ -1635,7 +1643,7 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
                 }
                 // (the polygons and cylinders a ray is left with go to the wave's queue of tests, as in the walk lane by lane)
                 if (pass) hl.template push_item<1>(S, i, src, ray, near, ignore, ctr);
-            } else {
+            } else if constexpr (CONE) {
                 if (live && bound_may_hit<BEHIND>(rec, src, un)) hl.template push_item<2>(S, i, src, ray, near, ignore, ctr);
             }
         }
@@ -1643,7 +1651,9 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
     if constexpr (POLY) {
         if (queued_kind == 1u) hl.template flush<1>(S, src, ray, near, ignore, ctr);
     }
-    if (queued_kind == 2u) hl.template flush<2>(S, src, ray, near, ignore, ctr);
+    if constexpr (CONE) {
+        if (queued_kind == 2u) hl.template flush<2>(S, src, ray, near, ignore, ctr);
+    }
     return true;
 }
 
@@ -1653,7 +1663,8 @@ RT_DEV bool beam_runs(const DevScene& S, F3 src, F3 ray, F3 un, float a, float n
 // point, `apex` (shadow rays); 3: as 1, for trees that partition well: only with at most RT_BEAM_MOST candidates, and a
 // wave it is not done for is walked leaf by leaf (KdWalk), which there costs less than finding all of a ray's hits.
 // POLY false: no polygon run with bounding records anywhere in the scene, and no code for one.
-template <int MODE, bool SHADOW, class Ctr, int BEAM = 0, bool POLY = true>
+// CONE false: no cone or cylinder in the scene, and no code for one.
+template <int MODE, bool SHADOW, class Ctr, int BEAM = 0, bool POLY = true, bool CONE = true>
 RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out, uint2* stack,
                              Ctr& ctr, float limit, F3 apex = F3{0.0f, 0.0f, 0.0f}) {
     static_assert(MODE == 1 || MODE == 2, "the hit-list walk goes by the bounding records");
@@ -1676,10 +1687,10 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     RT_HITSTAT(0, 1u);
     bool beamed = false;
     if constexpr (BEAM != 0)
-        beamed = beam_runs<BEAM == 2, MODE == 2, POLY>(S, src, ray, unit_ray(ray, tame ? a : 1.0f), a, near, ignore, tame, tame && in_root, hl, ctr,
+        beamed = beam_runs<BEAM == 2, MODE == 2, POLY, CONE>(S, src, ray, unit_ray(ray, tame ? a : 1.0f), a, near, ignore, tame, tame && in_root, hl, ctr,
                                                  lane_words, stride, apex, limit, BEAM == 3 ? (uint32_t)RT_BEAM_MOST : WQ_CAP, ri);
     if constexpr (BEAM == 3) {
-        if (!beamed) return in_root && kd_traverse_closest<MODE | (POLY ? 0 : 512), Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        if (!beamed) return in_root && kd_traverse_closest<MODE | (POLY ? 0 : 512) | (CONE ? 0 : 1024), Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
     }
     if (tame && in_root) {  // ---- (A)  the walk of a leaf (KdWalk::round), of the leaf that lists every primitive
         constexpr bool BEHIND = MODE == 2;
@@ -1704,19 +1715,23 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
             }
         }
         RT_PHASE(2);
-        if (S.all_w != 0xffffffffu) {  // cylinders (the cone items before q2.z)
-            const uint32_t cyl_n = __float_as_uint(S.bnd[S.all_w].w) >> 3;
-            leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec, ri);
-            hl.template flush<2>(S, src, ray, near, ignore, ctr);
+        if constexpr (CONE) {
+            if (S.all_w != 0xffffffffu) {  // cylinders (the cone items before q2.z)
+                const uint32_t cyl_n = __float_as_uint(S.bnd[S.all_w].w) >> 3;
+                leaf_run_lane<2, BEHIND, false>(S, q2.z - cyl_n, cyl_n, S.all_w, src, ray, un, a, near, ignore, hl, ctr, lane_words, stride, occ, hl, no_lrec, ri);
+                hl.template flush<2>(S, src, ray, near, ignore, ctr);
+            }
         }
         }
         RT_PHASE(3);
         // cones proper, which no record bounds: every lane tests every one (entries by scalar loads when they are many)
-        if (q2.w >= BIG_LEAF) {
-            leaf_cones<true, MODE>(S, q2.z, q2.w, src, ray, un, true, near, ignore, hl, ctr);
-            q2.w = 0u;
+        if constexpr (CONE) {
+            if (q2.w >= BIG_LEAF) {
+                leaf_cones<true, MODE>(S, q2.z, q2.w, src, ray, un, true, near, ignore, hl, ctr);
+                q2.w = 0u;
+            }
         }
-        leaf_runs<false, MODE, true>(S, q2, q3, src, ray, un, true, true, a, near, ignore, hl, ctr);  // what is left: short runs
+        leaf_runs<false, MODE, true, CONE>(S, q2, q3, src, ray, un, true, true, a, near, ignore, hl, ctr);  // what is left: short runs
         RT_PHASE(4);
     }
     bool r_hit = false;
@@ -1724,7 +1739,7 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
     RT_HITSTAT(2, n_hits);
     if (!tame || n_hits > HIT_CAP) {  // (rare)
         RT_HITSTAT(1, 1u);
-        if (in_root) r_hit = kd_traverse_closest<MODE | (POLY ? 0 : 512), Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        if (in_root) r_hit = kd_traverse_closest<MODE | (POLY ? 0 : 512) | (CONE ? 0 : 1024), Ctr, 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
         return r_hit;
     }
     uint32_t mask = (1u << n_hits) - 1u;
@@ -1816,7 +1831,7 @@ RT_DEV bool kd_traverse_hits(const DevScene& S, F3 src, F3 ray, float near, uint
         } else {
             LeafBest lb;
             lb.init();
-            if ((code >> 30) == 1u) cone_item<false>(S, i, src, ray, near, NO_PRIM, lb, ctr);
+            if (CONE && (code >> 30) == 1u) cone_item<false>(S, i, src, ray, near, NO_PRIM, lb, ctr);
             else polygon_item<false, true>(S, i, src, ray, near, NO_PRIM, lb, ctr);
             out.n = lb.n;
         }
@@ -1840,7 +1855,7 @@ template <int CULL, class Ctr, int OCC>
 RT_DEV bool kd_traverse_closest(const DevScene& S, F3 src, F3 ray, float near, uint32_t ignore, Hit& out,
                                 uint2* stack, Ctr& ctr, float limit) {
     if constexpr ((CULL & 64) != 0) {  // (+ 64: the hit-list walk)
-        return kd_traverse_hits<CULL & 3, false, Ctr, (CULL & 128) == 0 ? 0 : ((CULL & 256) != 0 ? 3 : 1), (CULL & 512) == 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
+        return kd_traverse_hits<CULL & 3, false, Ctr, (CULL & 128) == 0 ? 0 : ((CULL & 256) != 0 ? 3 : 1), (CULL & 512) == 0, (CULL & 1024) == 0>(S, src, ray, near, ignore, out, stack, ctr, limit);
     } else {
         KdDeep<(CULL & 4) == 0> deep;
         KdWalk<CULL, Ctr, OCC> w(S, stack, ctr, deep);
