@@ -95,10 +95,11 @@ def check_scene(rtamd, oracle, gpu_ctx, text, phong=True, depth=5, width=0, heig
     return st, fst
 
 
-def random_scene(seed, size=96):
+def random_scene(seed, size=96, kinds=None, count=(30, 160)):
     """Spheres, cylinders, cones, flat polygons of 3 to 7 vertices (some not convex) and patches
     with their own normals, scattered so that the reference's builder makes a real tree; two or
-    three lights, some mirrors, some glass."""
+    three lights, some mirrors, some glass.  kinds: the primitive kinds to draw from (0 sphere, 1 cylinder or
+    cone, 2-4 polygon, 5 patch) instead of all six."""
     rng = np.random.default_rng(seed)
     lines = ["v", "from 4.2 3.1 2.6", "at 0 0 0.2", "up 0 0 1", "angle 38", "hither 0.05", "resolution %d %d" % (size, size),
              "b 0.1 0.2 0.35"]
@@ -119,12 +120,14 @@ def random_scene(seed, size=96):
         for gy in range(-3, 3):
             lines += ["p 4", "%d %d -0.6" % (gx, gy), "%d %d -0.6" % (gx + 1, gy), "%d %d -0.6" % (gx + 1, gy + 1),
                       "%d %d -0.6" % (gx, gy + 1)]
-    for _ in range(int(rng.integers(30, 160))):
+    for _ in range(int(rng.integers(*count))):
         if rng.random() < 0.15:
             surface()
         c = rng.uniform(-1.6, 1.6, 3)
         s = 10.0 ** rng.uniform(-1.4, -0.5)
         kind = rng.integers(0, 6)
+        if kinds is not None:
+            kind = kinds[kind % len(kinds)]
         if kind == 0:
             lines.append("s %.7g %.7g %.7g %.7g" % (*c, s))
         elif kind == 1:  # cylinder or cone
@@ -165,6 +168,23 @@ def test_random_mixed_scenes(rtamd, oracle, gpu_ctx, seed):
     assert o.info.nodes > 9
     check_scene(rtamd, oracle, gpu_ctx, text, depth=6, fast_bar=None)
     check_scene(rtamd, oracle, gpu_ctx, text, phong=False, depth=2, work=False, fast_bar=None)
+
+
+FEW_KINDS = {"no cones": (0, 2, 5), "polygons": (2, 5), "no polygons": (0, 1), "cones": (1,), "spheres": (0,)}
+
+
+@pytest.mark.parametrize("seed", range(max(2, int(os.environ.get("RTAMD_FUZZ_SEEDS", "16")) // 8)))
+@pytest.mark.parametrize("kinds", sorted(FEW_KINDS))
+def test_random_scenes_of_few_kinds(rtamd, oracle, gpu_ctx, seed, kinds):
+    """As above with some primitive kinds left out, and up to 400 primitives, so that leaves are long enough for runs
+    with bounding records: the library has kernels of their own for scenes without a polygon run and for scenes
+    without a cone, and scenes of spheres alone run the lean kernels."""
+    text = random_scene(7000 + seed, kinds=FEW_KINDS[kinds], count=(60, 400))
+    try:
+        oracle.OracleScene(text)
+    except Exception as e:  # a scene on which the reference's builder does not terminate
+        pytest.skip(str(e))
+    check_scene(rtamd, oracle, gpu_ctx, text, depth=6, fast_bar=None)
 
 
 @pytest.mark.parametrize("name", REFERENCE_FIXTURES + EXTRA)
