@@ -364,12 +364,13 @@ def main():
     ms_per_step = elapsed_max / args.steps * 1e3
     value = rays_frame * args.steps / elapsed_max / 1e6
     # The dominant kernel: k_shadow (the frame's shadow rays, three quarters of all rays on balls).  Its
-    # algorithmic work = its own counters x the per-event FLOPs, its bytes = one 32-byte ray read and one
-    # 4-byte flag written per shadow ray plus what its tests request (cache-served); its duration = its
-    # launch in the serial-schedule frames above.
-    sh_flops = flops_of(work_shadow)
+    # algorithmic work = its own counters x the per-event FLOPs + the 12 operations that form a ray from its hit's
+    # queue entry and the light (3 sub, magnitude 6, 3 div), its bytes = that 16-byte entry read (the rays of a hit
+    # share it) and one 4-byte flag written per shadow ray plus what its tests request (cache-served); its
+    # duration = its launch in the serial-schedule frames above.
     sh_rays = work["rays_shadow"]
-    sh_bytes = sh_rays * (32 + 4) + sum(work_shadow.get(k, 0.0) * c for k, c in BYTES.items())
+    sh_flops = flops_of(work_shadow) + 12.0 * sh_rays
+    sh_bytes = sh_rays * (16 + 4) + sum(work_shadow.get(k, 0.0) * c for k, c in BYTES.items())
     sh_s = kernel_ms["ms_shadow"] * 1e-3 if kernel_ms["ms_shadow"] > 0 else float("nan")
     sh_traffic = traffic.get("k_shadow", {}).get("hbm_bytes_per_launch") if traffic else None
     # (the commit whose build the counters were taken on: stamped into the file by tools/keep_profile.py)

@@ -65,7 +65,7 @@ struct DevBuf {
 // (hipMalloc, grown on demand); the slot of the entry point that allocates nothing points into
 // the library's static device array instead.
 struct Workspace {
-    float4 *ray_o = nullptr, *ray_d = nullptr, *node_col = nullptr, *hit_a = nullptr, *sray_o = nullptr, *sray_d = nullptr;
+    float4 *ray_o = nullptr, *ray_d = nullptr, *node_col = nullptr, *hit_a = nullptr, *sray_o = nullptr;
     uint32_t *hit_p = nullptr, *sray_blocked = nullptr;
     uint2* node_sh = nullptr;
     uint4* node_kid = nullptr;
@@ -73,14 +73,15 @@ struct Workspace {
     uint32_t* levels = nullptr;
     unsigned long long* counters = nullptr;
     size_t pool_cap = 0;    // ray-tree nodes
-    size_t shadow_cap = 0;  // shadow-ray slots, all lights' queues together
+    size_t shadow_slots = 0;  // lit hits the shadow queue holds (sray_o: a hit's point and primitive, once for all lights)
+    size_t shadow_cap = 0;    // shadow rays, all lights' together (sray_blocked)
 };
 
 // Everything one frame in flight owns.  A context has four, so that the small, latency-bound
 // launches at the end of one frame can run beside the big first launches of the next.
 struct FrameSlot {
     // workspace, kept across frames and grown on demand
-    DevBuf<float4> ray_o, ray_d, node_col, hit_a, sray_o, sray_d;
+    DevBuf<float4> ray_o, ray_d, node_col, hit_a, sray_o;
     DevBuf<uint32_t> hit_p, sray_blocked;
     DevBuf<uint2> node_sh;
     DevBuf<uint4> node_kid;
@@ -233,7 +234,11 @@ float bits_to_float(uint32_t u) {
 }
 
 constexpr size_t NODE_BYTES = 4 * sizeof(float4) + sizeof(uint4) + sizeof(uint32_t) + sizeof(uint2);  // per ray-tree node
-constexpr size_t SHADOW_BYTES = 2 * sizeof(float4) + sizeof(uint32_t);                                 // per shadow-ray slot
+constexpr size_t SHADOW_SLOT_BYTES = sizeof(float4);  // per lit hit: the queue entry its shadow rays share
+constexpr size_t SHADOW_RAY_BYTES = sizeof(uint32_t);  // per lit hit and light: the ray's answer
+size_t shadow_bytes(size_t slots, size_t rays) { return slots * SHADOW_SLOT_BYTES + rays * SHADOW_RAY_BYTES; }
+// lit hits a workspace holds when a scene has `lights1` lights
+size_t shadow_slots_of(size_t slots, size_t rays, size_t lights1) { return std::min(slots, rays / lights1); }
 
 // Both leave the slot consistent when an allocation fails: the whole set released, capacity 0.
 int ensure_pool(rt_context* ctx, FrameSlot& f, size_t cap) {
@@ -259,20 +264,30 @@ int ensure_pool(rt_context* ctx, FrameSlot& f, size_t cap) {
     return RT_OK;
 }
 
-int ensure_shadow(rt_context* ctx, FrameSlot& f, size_t cap) {
-    if (f.ws.shadow_cap >= cap) return RT_OK;
+int ensure_shadow(rt_context* ctx, FrameSlot& f, size_t slots, size_t lights1) {
+    const size_t cap = slots * lights1;
+    if (f.ws.shadow_slots >= slots && f.ws.shadow_cap >= cap) return RT_OK;
     if (f.fixed) return fail(ctx, RT_ERR_CAPACITY, "the static workspace holds fewer shadow rays than this frame needs");
-    f.ws.shadow_cap = 0;
-    hipError_t e = f.sray_o.alloc(cap);
-    if (e == hipSuccess) e = f.sray_d.alloc(cap);
-    if (e == hipSuccess) e = f.sray_blocked.alloc(cap);
+    // (each array only ever grows: a scene with fewer lights and more hits keeps the answers' array)
+    const size_t new_slots = std::max(slots, f.ws.shadow_slots), new_cap = std::max(cap, f.ws.shadow_cap);
+    hipError_t e = hipSuccess;
+    if (new_slots != f.ws.shadow_slots) {
+        f.ws.shadow_slots = 0;
+        e = f.sray_o.alloc(new_slots);
+    }
+    if (e == hipSuccess && new_cap != f.ws.shadow_cap) {
+        f.ws.shadow_cap = 0;
+        e = f.sray_blocked.alloc(new_cap);
+    }
     if (e != hipSuccess) {
-        f.sray_o.release(); f.sray_d.release(); f.sray_blocked.release();
+        f.sray_o.release(); f.sray_blocked.release();
+        f.ws.shadow_slots = f.ws.shadow_cap = 0;
         (void)hipGetLastError();
         return fail(ctx, RT_ERR_DEVICE, std::string("shadow queues of ") + std::to_string(cap) + " rays: " + hipGetErrorString(e));
     }
-    f.ws.sray_o = f.sray_o.p; f.ws.sray_d = f.sray_d.p; f.ws.sray_blocked = f.sray_blocked.p;
-    f.ws.shadow_cap = cap;
+    f.ws.sray_o = f.sray_o.p; f.ws.sray_blocked = f.sray_blocked.p;
+    f.ws.shadow_slots = new_slots;
+    f.ws.shadow_cap = new_cap;
     return RT_OK;
 }
 
@@ -903,26 +918,26 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     if (cap > 0xf0000000ull || scap * p.lights1 > 0xf0000000ull)
         return fail(ctx, RT_ERR_CAPACITY, "ray pool would exceed 2^32 entries");
     if (!f.fixed && ctx->workspace_limit != 0 &&
-        (uint64_t)cap * NODE_BYTES + (uint64_t)scap * p.lights1 * SHADOW_BYTES <= ctx->workspace_limit &&
-        (uint64_t)f.ws.pool_cap * NODE_BYTES + (uint64_t)f.ws.shadow_cap * SHADOW_BYTES > ctx->workspace_limit) {
+        (uint64_t)cap * NODE_BYTES + shadow_bytes(scap, scap * p.lights1) <= ctx->workspace_limit &&
+        (uint64_t)f.ws.pool_cap * NODE_BYTES + shadow_bytes(f.ws.shadow_slots, f.ws.shadow_cap) > ctx->workspace_limit) {
         // The slot holds more than the limit allows -- pools grown for an earlier, larger frame, before
         // the limit was lowered -- and this frame fits it: the pools are given back and made anew.
         f.ray_o.release(); f.ray_d.release(); f.node_col.release(); f.node_kid.release();
         f.hit_a.release(); f.hit_p.release(); f.node_sh.release();
-        f.sray_o.release(); f.sray_d.release(); f.sray_blocked.release();
+        f.sray_o.release(); f.sray_blocked.release();
         f.ws.pool_cap = 0;
-        f.ws.shadow_cap = 0;
+        f.ws.shadow_slots = f.ws.shadow_cap = 0;
     }
     if (!f.fixed && ctx->workspace_limit != 0 &&
-        (uint64_t)std::max(cap, f.ws.pool_cap) * NODE_BYTES + (uint64_t)std::max(scap * p.lights1, f.ws.shadow_cap) * SHADOW_BYTES >
+        (uint64_t)std::max(cap, f.ws.pool_cap) * NODE_BYTES + shadow_bytes(std::max(scap, f.ws.shadow_slots), std::max(scap * p.lights1, f.ws.shadow_cap)) >
             ctx->workspace_limit)
         return fail(ctx, RT_ERR_CAPACITY,
-                    "this frame needs " + std::to_string((cap * NODE_BYTES + scap * p.lights1 * SHADOW_BYTES) >> 20) +
+                    "this frame needs " + std::to_string((cap * NODE_BYTES + shadow_bytes(scap, scap * p.lights1)) >> 20) +
                         " MiB of ray pools, more than the workspace limit of " + std::to_string(ctx->workspace_limit >> 20) +
                         " MiB per frame slot (rt_context_set_workspace_limit, RTAMD_WORKSPACE_MAX_MB)");
     int rc = ensure_pool(ctx, f, cap);
     if (rc != RT_OK) return rc;
-    rc = ensure_shadow(ctx, f, scap * p.lights1);
+    rc = ensure_shadow(ctx, f, scap, p.lights1);
     if (rc != RT_OK) return rc;
 
     FrameArgs A;
@@ -958,9 +973,8 @@ int enqueue_frame(rt_context* ctx, FrameSlot& f, const FramePlan& p, size_t cap,
     A.node_kid = ws.node_kid;
     A.pool_cap = (uint32_t)ws.pool_cap;
     A.sray_o = ws.sray_o;
-    A.sray_d = ws.sray_d;
     A.sray_blocked = ws.sray_blocked;
-    A.shadow_cap = (uint32_t)(ws.shadow_cap / p.lights1);
+    A.shadow_cap = (uint32_t)shadow_slots_of(ws.shadow_slots, ws.shadow_cap, p.lights1);
     A.level_count = ws.levels;
     A.level_base = ws.levels + RT_MAX_LEVELS;
     A.shadow_count = ws.levels + LV_SHADOW_COUNT;
@@ -1157,7 +1171,7 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
     for (uint32_t attempt = 0;; ++attempt) {
         RT_HIP(ctx, hipEventSynchronize(f.ev_done));
         memcpy(lv, f.h_levels, sizeof(lv));
-        const size_t shadow_cap1 = f.ws.shadow_cap / p.lights1;
+        const size_t shadow_cap1 = shadow_slots_of(f.ws.shadow_slots, f.ws.shadow_cap, p.lights1);
         uint64_t need = p.n_slots, sneed = 0;
         for (uint32_t l = 0; l <= opt->max_depth; ++l) sneed += lv[LV_SHADOW_COUNT + l];
         for (uint32_t l = 1; l <= opt->max_depth + 1 && l < RT_MAX_LEVELS; ++l) need += lv[l];
@@ -1219,7 +1233,7 @@ int finish_frame(rt_context* ctx, FrameSlot& f, rt_stats* stats_out) {
         }
         stats.kernel_shadow = f.variant_shadow;
         stats.kernel_deep = f.variant_deep;
-        stats.workspace_bytes = (uint64_t)f.ws.pool_cap * NODE_BYTES + (uint64_t)f.ws.shadow_cap * SHADOW_BYTES;
+        stats.workspace_bytes = (uint64_t)f.ws.pool_cap * NODE_BYTES + shadow_bytes(f.ws.shadow_slots, f.ws.shadow_cap);
         stats.ray_nodes = p.n_slots;
         stats.levels = 1;
         for (uint32_t l = 1; l <= opt->max_depth; ++l) {
@@ -1344,7 +1358,7 @@ int begin_frame(rt_context* ctx, const rt_scene* scene, const rt_view* view, con
     // twenty views round the scene with four frames in flight: 3.6 -> 1.8 ms per frame.)
     auto wanted = [&](size_t have, size_t want) { return known && have < want - want / 8 ? want : have; };
     const size_t cap = std::max(wanted(f.ws.pool_cap, ctx->want_pool), floor_cap);
-    const size_t scap = std::max(wanted(f.ws.shadow_cap / p.lights1, ctx->want_shadow1), floor_cap);
+    const size_t scap = std::max(wanted(shadow_slots_of(f.ws.shadow_slots, f.ws.shadow_cap, p.lights1), ctx->want_shadow1), floor_cap);
     // Any other frame is waited for here, pools grown and the frame re-run as often as it takes, so that
     // what the caller queues on `stream` after this call finds the finished image.
     rc = enqueue_frame(ctx, f, p, cap, scap);
@@ -1424,7 +1438,7 @@ extern "C" int rt_render_device_static(rt_context* ctx, const rt_scene* scene, c
     // multiple of 64, which keeps every array on a 256-byte boundary.
     constexpr size_t HEAD = 4096;
     static_assert(LV_WORDS * sizeof(uint32_t) <= 2048 && N_COUNTERS * sizeof(unsigned long long) <= 2048, "counters fit the head");
-    const size_t per_entry = NODE_BYTES + SHADOW_BYTES * p.lights1;
+    const size_t per_entry = NODE_BYTES + SHADOW_SLOT_BYTES + SHADOW_RAY_BYTES * p.lights1;
     const size_t cap = ((RT_STATIC_WORKSPACE_BYTES - HEAD) / per_entry) & ~(size_t)63;
     if (cap < p.n_slots || cap < 64)
         return fail(ctx, RT_ERR_CAPACITY,
@@ -1444,10 +1458,10 @@ extern "C" int rt_render_device_static(rt_context* ctx, const rt_scene* scene, c
     ws.node_kid = (uint4*)take(cap * sizeof(uint4));
     ws.node_sh = (uint2*)take(cap * sizeof(uint2));
     ws.hit_p = (uint32_t*)take(cap * sizeof(uint32_t));
-    ws.sray_o = (float4*)take(cap * p.lights1 * sizeof(float4));
-    ws.sray_d = (float4*)take(cap * p.lights1 * sizeof(float4));
+    ws.sray_o = (float4*)take(cap * sizeof(float4));
     ws.sray_blocked = (uint32_t*)take(cap * p.lights1 * sizeof(uint32_t));
     ws.pool_cap = cap;
+    ws.shadow_slots = cap;
     ws.shadow_cap = cap * p.lights1;
     if ((size_t)(at - ctx->scratch_ptr) > RT_STATIC_WORKSPACE_BYTES) return fail(ctx, RT_ERR_CAPACITY, "static workspace layout");
     choose_level0(ctx, f, p);

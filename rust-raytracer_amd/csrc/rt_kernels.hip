@@ -199,19 +199,30 @@ RT_DEV Spawn spawn_of(const FrameArgs& A, const Ray& ray, const Hit& hit, bool i
 
 // One shadow ray per light for a front-face hit at `pos` (src/scene.rs:103-112), into slot `first` of
 // every light's queue.
+// The queue keeps what the rays of a hit share, its point and its primitive, once; k_shadow forms each light's ray
+// from that (a sixth of the bytes with one light, a twelfth and less with several, written here and read there).
 template <class Ctr>
 RT_DEV void put_shadow_rays(const FrameArgs& A, F3 pos, uint32_t hit_prim, uint32_t first, Ctr& ctr) {
-    const DevScene& S = A.scene;
-    for (uint32_t l = 0; l < S.n_lights; ++l) {
-        ctr.light_evals(1);
-        const float4 lp = S.lights[l * 2];
-        const F3 to_light = sub(f3(lp.x, lp.y, lp.z), pos);
-        const float ldist = magnitude(to_light);
-        const F3 ldir = divs(to_light, ldist);
-        const uint64_t s = (uint64_t)l * A.shadow_cap + first;
-        A.sray_o[s] = make_float4(pos.x, pos.y, pos.z, ldist);
-        A.sray_d[s] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(hit_prim));
-    }
+    ctr.light_evals(A.scene.n_lights);
+    A.sray_o[first] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(hit_prim));
+}
+// The shadow ray of queue slot `slot` towards light `light` (src/scene.rs:103-112): origin, direction, the light's
+// distance, the primitive to ignore.
+struct ShadowRay {
+    F3 o, d;
+    float dist;
+    uint32_t ignore;
+};
+RT_DEV ShadowRay shadow_ray_of(const FrameArgs& A, uint32_t light, uint32_t slot) {
+    const float4 p = A.sray_o[slot];
+    const float4 lp = A.scene.lights[light * 2u];
+    ShadowRay r;
+    r.o = f3(p.x, p.y, p.z);
+    const F3 to_light = sub(f3(lp.x, lp.y, lp.z), r.o);
+    r.dist = magnitude(to_light);
+    r.d = divs(to_light, r.dist);
+    r.ignore = __float_as_uint(p.w);
+    return r;
 }
 
 // A spawned ray in its pool slot.  Until the ray is traced, the slot's hit_p word holds the ray's level
@@ -684,35 +695,32 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
     constexpr bool LEAN = (CULL & 4) != 0, STAYS = (CULL & 8) != 0;
     const uint32_t n = end > first ? end - first : 0u;  // slots of one light's queue in this launch
     // Lean kernels: 64 rays at a time, every lane its own walk from start to end.
-    auto trace = [&](uint64_t i) {
-        const float4 so = A.sray_o[i];
-        const float4 sd = A.sray_d[i];
+    auto trace = [&](uint32_t light, uint32_t slot) {
+        const ShadowRay sr = shadow_ray_of(A, light, slot);
         Hit blocker;
         bool blocked = false;
         bool found;
         if constexpr ((CULL & 64) != 0) {
-            const float4 lp = S.lights[((CULL & 8) != 0 ? (uint32_t)(i / A.shadow_cap) : blockIdx.y) * 2u];  // (one light's rays per wave)
-            found = kd_traverse_hits<CULL & 3, true, Ctr, (CULL & 128) != 0 ? 2 : 0, (CULL & 512) == 0, (CULL & 1024) == 0>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f,
-                                                                                   __float_as_uint(sd.w), blocker, lds_stack, ctr, so.w,
+            const float4 lp = S.lights[light * 2u];  // (one light's rays per wave)
+            found = kd_traverse_hits<CULL & 3, true, Ctr, (CULL & 128) != 0 ? 2 : 0, (CULL & 512) == 0, (CULL & 1024) == 0>(S, sr.o, sr.d, 0.0f, sr.ignore, blocker, lds_stack, ctr, sr.dist,
                                                                                    f3(lp.x, lp.y, lp.z));
         } else {
-            found = kd_traverse_closest<CULL, Ctr, OCC>(S, f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w),
-                                                        blocker, lds_stack, ctr, so.w);
+            found = kd_traverse_closest<CULL, Ctr, OCC>(S, sr.o, sr.d, 0.0f, sr.ignore, blocker, lds_stack, ctr, sr.dist);
         }
-        if (found) blocked = blocker.dist <= so.w;
-        A.sray_blocked[i] = blocked ? 1u : 0u;
+        if (found) blocked = blocker.dist <= sr.dist;
+        A.sray_blocked[(uint64_t)light * A.shadow_cap + slot] = blocked ? 1u : 0u;
     };
-    // Position w of the launch's rays (light after light, `n` slots each) in the queue arrays.
-    auto slot_of = [&](uint32_t w) -> uint64_t {
+    // Ray w of the launch (light after light, `n` slots each): its light and its slot.
+    auto slot_of = [&](uint32_t w) -> uint2 {
         const uint32_t light = w / n;
-        return (uint64_t)light * A.shadow_cap + first + (w - light * n);
+        return make_uint2(light, first + (w - light * n));
     };
     // The other kernels: a wave owns a run of consecutive rays at a time, and a lane whose ray is
     // finished takes the run's next one between two rounds of the walk (once RT_SHADOW_REFILL lanes are
     // idle, which makes the fetch worth its instructions): in trees of small leaves rays differ widely
     // in the number of rounds they take, and a lane that waited for the slowest of its 64 would idle
     // half the time.  (A run of 64 rays is a wave that traces 64 rays and is done.)
-    auto trace_run = [&](KdWalk<CULL & ~64, Ctr, OCC>& w, uint32_t c0, uint32_t c_end, uint64_t queue, bool linear) {
+    auto trace_run = [&](KdWalk<CULL & ~64, Ctr, OCC>& w, uint32_t c0, uint32_t c_end, uint32_t run_light, bool linear) {
         uint32_t next = c0;
         bool have = false;
         uint64_t mine = 0;
@@ -724,12 +732,12 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
                 const uint32_t idx = next + prefix_count(idle);
                 next += n_idle;
                 if (!have && idx < c_end) {
-                    const uint64_t at = linear ? slot_of(idx) : queue + idx;
-                    const float4 so = A.sray_o[at];
-                    const float4 sd = A.sray_d[at];
-                    w.begin(f3(so.x, so.y, so.z), f3(sd.x, sd.y, sd.z), 0.0f, __float_as_uint(sd.w), so.w);
+                    const uint2 ls = linear ? slot_of(idx) : make_uint2(run_light, idx);
+                    const uint64_t at = (uint64_t)ls.x * A.shadow_cap + ls.y;
+                    const ShadowRay sr = shadow_ray_of(A, ls.x, ls.y);
+                    w.begin(sr.o, sr.d, 0.0f, sr.ignore, sr.dist);
                     mine = at;
-                    limit = so.w;
+                    limit = sr.dist;
                     if (w.done) A.sray_blocked[at] = 0u;  // (misses the scene's box)
                     else have = true;
                 }
@@ -764,24 +772,25 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_SHADOW_WAVES) k_shadow(Frame
             if constexpr (LEAN) {
                 for (uint32_t part = 0; part < LEAN_TAKE && c + part < total; part += 64u) {
                     const uint32_t i = c + part + lane_id();
-                    if (i < total) trace(slot_of(i));
+                    if (i < total) {
+                        const uint2 ls = slot_of(i);
+                        trace(ls.x, ls.y);
+                    }
                 }
             } else {
                 const uint32_t c_end = LEAN_TAKE < total - c ? c + LEAN_TAKE : total;
                 const uint32_t run = chunk > 64u ? LEAN_TAKE : 64u;  // (lanes take new rays only in scenes where that pays)
-                for (uint32_t part = c; part < c_end; part += run) trace_run(w, part, run < c_end - part ? part + run : c_end, 0, true);
+                for (uint32_t part = c; part < c_end; part += run) trace_run(w, part, run < c_end - part ? part + run : c_end, 0u, true);
             }
         }
     } else if constexpr (RT_SHADOW_REFILL != 0 && !LEAN && (CULL & 64) == 0) {
-        const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
         const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
         KdDeep<!LEAN> deep;
         KdWalk<CULL & ~64, Ctr, OCC> w(S, lds_stack, ctr, deep);
         for (uint64_t c0 = (uint64_t)first + (uint64_t)wave * chunk; c0 < end; c0 += (uint64_t)n_waves * chunk)
-            trace_run(w, (uint32_t)c0, c0 + chunk < end ? (uint32_t)c0 + chunk : end, queue, false);
+            trace_run(w, (uint32_t)c0, c0 + chunk < end ? (uint32_t)c0 + chunk : end, blockIdx.y, false);  // blockIdx.y = light
     } else {
-        const uint64_t queue = (uint64_t)blockIdx.y * A.shadow_cap;  // blockIdx.y = light
-        for (uint32_t k = first + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) trace(queue + k);
+        for (uint32_t k = first + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) trace(blockIdx.y, k);  // blockIdx.y = light
     }
     flush_work<24>(A, ctr);
 }

@@ -127,10 +127,9 @@ struct FrameArgs {
     uint32_t* deep_max;     // fused: the deepest level that held a ray
     uint32_t deep_exit_polls;  // fused: looks at an empty stack after which an idle wave of k_deep leaves for good (0: it stays to the end)
     // shadow-ray queue of the frame
-    float4* sray_o;         // origin.xyz, distance to the light
-    float4* sray_d;         // direction.xyz, bits(ignored primitive)
-    uint32_t* sray_blocked; // 1 = a primitive lies between the surface and the light
-    uint32_t shadow_cap;    // slots per light's queue; light l owns [l * shadow_cap, (l + 1) * shadow_cap)
+    float4* sray_o;         // [shadow_cap] per lit hit: its point, bits(its primitive) -- what its shadow rays share (k_shadow forms each light's ray)
+    uint32_t* sray_blocked; // per ray: 1 = a primitive lies between the surface and the light; light l owns [l * shadow_cap, (l + 1) * shadow_cap)
+    uint32_t shadow_cap;    // lit hits the queue holds
     uint32_t* shadow_count; // [RT_MAX_LEVELS] lit hits of each level (each takes one slot in every queue);
                             // a level's slots follow those of the levels before it
     uint32_t* overflow;
