@@ -297,7 +297,7 @@ int rt_context_set_workspace_limit(rt_context* ctx, uint64_t bytes_per_frame_slo
  * RT_STATIC_WORKSPACE_BYTES that each GPU the library runs on holds from load to exit, and the
  * call allocates and frees nothing (streams, events and pinned counters were made by
  * rt_context_create).  A frame whose rays do not fit -- about RT_STATIC_WORKSPACE_BYTES /
- * (92 + 36 * lights) ray-tree nodes, camera rays included -- fails with RT_ERR_CAPACITY and
+ * (108 + 4 * lights) ray-tree nodes, camera rays included -- fails with RT_ERR_CAPACITY and
  * writes nothing to the outputs; it is never re-run with more room.  Every call on one GPU, from
  * any context, works in the same array: calls that overlap on one GPU race.  Returns after the
  * frame has completed. */
