@@ -90,7 +90,7 @@ def balls(size: int = 4, width: int = 512, height: int = 512) -> str:
 
 
 def tetra(size: int = 6, width: int = 512, height: int = 512) -> str:
-    """Sierpinski tetrahedron: 4^size triangles (``p 3``), one light."""
+    """Sierpinski tetrahedron: 4^size triangles (``p 3``) facing outwards, two lights."""
     out = _view((1.022846, -3.177154, -2.174512), (-0.004103, -0.004103, 0.216539), (-0.816497, -0.816497, 0.816497),
                 45, 1.0, (width, height))
     out.append("b 0.078 0.361 0.753")
@@ -107,7 +107,9 @@ def tetra(size: int = 6, width: int = 512, height: int = 512) -> str:
                 (cx - s, cy + s, cz - s),
                 (cx - s, cy - s, cz + s),
             ]
-            for a, b, c in ((0, 1, 3), (0, 2, 1), (0, 3, 2), (1, 2, 3)):
+            # (counter-clockwise as seen from outside: the reference takes (v1 - v0) x (v2 - v0) for the front,
+            # src/polygon.rs:61-63, and shades no back face)
+            for a, b, c in ((0, 3, 1), (0, 1, 2), (0, 2, 3), (1, 3, 2)):
                 tris.append((p[a], p[b], p[c]))
             return
         h = s / 2.0
