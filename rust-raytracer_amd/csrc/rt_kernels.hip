@@ -197,6 +197,9 @@ RT_DEV Spawn spawn_of(const FrameArgs& A, const Ray& ray, const Hit& hit, bool i
     return sp;
 }
 
+// node_sh.y of a lit hit
+constexpr uint32_t SH_NO_CHILD = 1u, SH_REFLECTS = 2u;
+
 // One shadow ray per light for a front-face hit at `pos` (src/scene.rs:103-112), into slot `first` of
 // every light's queue.
 // The queue keeps what the rays of a hit share, its point and its primitive, once; k_shadow forms each light's ray
@@ -369,7 +372,8 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_intersect(Fra
             const uint32_t first = slot0 + prefix_count(m_lit);
             const bool fits = slot0 + c_lit <= A.shadow_cap;
             if (!fits) *A.overflow = 1u;
-            A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
+            // (.y: what k_light needs to know of the node's children, so that it reads neither node_kid nor node_col)
+            A.node_sh[node] = make_uint2(fits ? first : NONE, (want_refl || want_refr ? 0u : SH_NO_CHILD) | (want_refl ? SH_REFLECTS : 0u));
             if (fits) put_shadow_rays(A, pos, hit.prim, first, ctr);
         }
         if (i < count && !lit) A.node_sh[node] = make_uint2(NONE, 0u);  // also the padding slots of edge tiles
@@ -607,7 +611,7 @@ __global__ void __launch_bounds__(RT_LEAN_BLOCK, RT_TRACE_WAVES) k_deep(FrameArg
             const uint32_t first = slot0 + prefix_count(m_lit);
             const bool fits = slot0 + c_lit <= A.shadow_cap;
             if (!fits) atomicMax(A.overflow, 1u);
-            A.node_sh[node] = make_uint2(fits ? first : NONE, A.shadow_cap);
+            A.node_sh[node] = make_uint2(fits ? first : NONE, (want_refl || want_refr ? 0u : SH_NO_CHILD) | (want_refl ? SH_REFLECTS : 0u));
             if (fits) put_shadow_rays(A, pos, hit.prim, first, ctr);
         }
         if (active && !lit) A.node_sh[node] = make_uint2(NONE, 0u);
@@ -819,7 +823,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t first_
         F3 total = f3(0.0f, 0.0f, 0.0f);
         const F3 pos = add(ray.src, mul(ray.dir, ha.w));  // src/scene.rs:95
         for (uint32_t l = 0; l < S.n_lights; ++l) {  // src/scene.rs:103-125, in light order
-            const uint64_t s = (uint64_t)l * sh.y + sh.x;
+            const uint64_t s = (uint64_t)l * A.shadow_cap + sh.x;
             if (A.sray_blocked[s] == 0u) {
                 ctr.shade_evals(1);
                 // the direction to the light, formed again as k_intersect formed it for the shadow ray (the same
@@ -834,15 +838,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_light(FrameArgs A, uint32_t first_
                 total = add(total, direct);
             }
         }
-        const uint4 kid = A.node_kid[node];
-        if (kid.x == NONE && kid.y == NONE) {  // no children: final already (src/scene.rs:195)
+        if ((sh.y & SH_NO_CHILD) != 0u) {  // no children: final already (src/scene.rs:195)
             total.x = total.x > 1.0f ? 1.0f : total.x;
             total.y = total.y > 1.0f ? 1.0f : total.y;
             total.z = total.z > 1.0f ? 1.0f : total.z;
         }
-        float4 col = A.node_col[node];
-        col.x = total.x; col.y = total.y; col.z = total.z;
-        A.node_col[node] = col;
+        // (.w: the weight of the reflection child, as k_intersect / k_deep wrote it: Spawn::reflectance)
+        A.node_col[node] = make_float4(total.x, total.y, total.z, (sh.y & SH_REFLECTS) != 0u ? surf.reflectance : 0.0f);
     }
     flush_work(A, ctr);
 }

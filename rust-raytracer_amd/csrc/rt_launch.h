@@ -113,7 +113,7 @@ struct FrameArgs {
     float4* ray_d;     // direction.xyz, bits(ignore primitive)
     float4* hit_a;     // closest hit: normal.xyz, distance
     uint32_t* hit_p;   // closest hit: primitive, 0xffffffff = miss
-    uint2* node_sh;    // shadow rays of this node's hit: {slot in every light's queue, slots per queue}
+    uint2* node_sh;    // shadow rays of this node's hit: {slot in every light's queue or none, 1: the node has no child | 2: it has a reflection child}
     float4* node_col;  // direct (later total) colour, reflectance weight
     uint4* node_kid;   // reflection child, refraction child, bits(transmittance weight), hit flag
     uint32_t pool_cap;
